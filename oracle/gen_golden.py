@@ -1,0 +1,195 @@
+"""Generate tests/golden/*.npz by running the REAL reference (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage:  python oracle/gen_golden.py
+Imports /root/reference through oracle/ref_import.py (stub mmengine/mmcv/timm,
+SURVEY.md §8c), fills it with the formula weights of bde2vid_amd/weights.py, runs it
+on seeded inputs and stores ONLY: the config, the seeds and the reference's outputs.
+No weights and no reference source are stored; inputs are regenerated from the seeds
+by `golden_inputs` (shared with the tests).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from bde2vid_amd.config import GeneratorConfig, canonical  # noqa: E402
+from oracle import ref_import, voxel_oracle  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+WEIGHT_SEED = 4   # chosen so every golden case has a well-spread (unsaturated) sigmoid output
+
+
+# ---------------------------------------------------------------- shared with tests
+def voxel_like(shape, seed):
+    """Direct-voxel synthetic input: N(0,1)*0.5 with ~70 % zeros."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.5)
+    keep = rng.random(shape, dtype=np.float32) > np.float32(0.7)
+    return (x * keep).astype(np.float32)
+
+
+def dense_like(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def golden_inputs(T, B, num_bins, H, W, seed):
+    return [voxel_like((B, num_bins, H, W), seed + t) for t in range(T)]
+
+
+E2E_CASES = {
+    # name: (config kwargs, H, W, T, B, input seed)
+    'e2e_tiny': (dict(basechannels=8, depths=(2, 0, 2), num_heads=4), 56, 64, 5, 1, 100),
+    'e2e_buf5': (dict(basechannels=16, depths=(1, 2, 3), num_heads=8,
+                      buffer_index=(-2, -1, 0, 1, 2), q_idx=2), 64, 80, 6, 1, 200),
+    'e2e_T1': (dict(basechannels=8, depths=(2, 0, 2), num_heads=4), 72, 56, 1, 1, 300),
+    'e2e_T2': (dict(basechannels=8, depths=(2, 0, 2), num_heads=4), 72, 56, 2, 1, 310),
+    'e2e_B2': (dict(basechannels=8, depths=(2, 0, 2), num_heads=4), 56, 72, 3, 2, 400),
+    'e2e_cfgA_small': (dict(), 56, 64, 3, 1, 500),          # canonical channels/heads/depths
+    'e2e_ks3': (dict(basechannels=8, ks=3, depths=(1, 0, 2), num_heads=2), 64, 56, 3, 1, 600),
+}
+CFGA_FULL = ('e2e_cfgA_184x240', dict(), 184, 240, 4, 1, 700, 4)   # stored at pixel stride 4
+
+
+def _cfg(kw):
+    return GeneratorConfig(**kw)
+
+
+def gen_e2e():
+    for name, (kw, H, W, T, B, seed) in E2E_CASES.items():
+        cfg = _cfg(kw)
+        model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+        xs = golden_inputs(T, B, cfg.num_bins, H, W, seed)
+        with torch.no_grad():
+            ys = model([{'events': torch.from_numpy(x)} for x in xs])
+        y = torch.stack(ys).numpy()
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), out=y,
+                            meta=json.dumps(dict(cfg=cfg.to_dict(), H=H, W=W, T=T, B=B, seed=seed,
+                                                 weight_seed=WEIGHT_SEED)))
+        print(name, y.shape, float(y.mean()), float(y.std()))
+    name, kw, H, W, T, B, seed, stride = CFGA_FULL
+    cfg = _cfg(kw)
+    model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+    xs = golden_inputs(T, B, cfg.num_bins, H, W, seed)
+    with torch.no_grad():
+        ys = model([{'events': torch.from_numpy(x)} for x in xs])
+    y = torch.stack(ys).numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), out=y[..., ::stride, ::stride],
+                        mean=y.mean(axis=(1, 2, 3, 4)), std=y.std(axis=(1, 2, 3, 4)),
+                        meta=json.dumps(dict(cfg=cfg.to_dict(), H=H, W=W, T=T, B=B, seed=seed,
+                                             weight_seed=WEIGHT_SEED, stride=stride)))
+    print(name, y.shape, float(y.mean()), float(y.std()))
+
+
+def gen_blocks():
+    """Each building block in isolation, called on the reference's own module objects."""
+    cfg = _cfg(dict(basechannels=16, depths=(2, 0, 3), num_heads=8))
+    model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+    g = model.generator
+    out = {}
+    with torch.no_grad():
+        # ConvLayer stride 1 (head)  -- submodules.py:105-114
+        x = torch.from_numpy(voxel_like((1, 5, 24, 32), 11))
+        out['head'] = g.head(x).numpy()
+        # RecurrentConv: ConvLayer stride 2 + ConvLSTM, 3 consecutive steps from zero state
+        enc = g.forward_encoder[0]
+        enc.state = None
+        seq = [torch.from_numpy(dense_like((1, 16, 24, 32), 20 + t)) for t in range(3)]
+        out['rc_h'] = np.stack([enc(s).numpy() for s in seq])
+        out['rc_c'] = enc.state[1].numpy()
+        enc.state = None
+        # bare ConvLayer stride 2
+        out['enc_conv'] = enc.conv(seq[0]).numpy()
+        # UpsampleConvLayer (decoder 0: 128 -> 64 channels at bc=16)
+        x = torch.from_numpy(dense_like((1, 128, 9, 11), 30))
+        out['upconv'] = g.decoders[0](x).numpy()
+        # predI + sigmoid
+        x = torch.from_numpy(dense_like((2, 16, 10, 12), 40))
+        out['predI'] = g.activation(g.predI(x)).numpy()
+        # DFrameAttention level 0 (C=32, depth 2: plain + dilated), non-multiple-of-7 map
+        buf = [torch.from_numpy(dense_like((1, 32, 17, 23), 50 + d)) for d in range(3)]
+        out['attn_l0'] = g.feat_attns[0](list(buf)).numpy()
+        blk0, blk1 = g.feat_attns[0].blocks[0], g.feat_attns[0].blocks[1]
+        out['swin_plain'] = blk0(torch.stack(buf)).numpy()
+        out['swin_dilated'] = blk1(torch.stack(buf)).numpy()
+        out['swin_plain_part1'] = blk0.forward_part1(torch.stack(buf)).numpy()
+        out['swin_dilated_part1'] = blk1.forward_part1(torch.stack(buf)).numpy()
+        # level 2 (C=128, depth 3), B=2, map exactly 7 high
+        buf = [torch.from_numpy(dense_like((2, 128, 7, 9), 60 + d)) for d in range(3)]
+        out['attn_l2'] = g.feat_attns[2](list(buf)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'blocks.npz'), **out,
+                        meta=json.dumps(dict(cfg=cfg.to_dict(), weight_seed=WEIGHT_SEED)))
+    print('blocks', {k: v.shape for k, v in out.items()})
+
+
+VOXEL_CASES = {
+    # name: (N, H, W, seed, special)
+    'n3': (3, 20, 30, 1, None),
+    'n1k_dups': (1000, 60, 80, 2, 'dups'),
+    'n50k': (50000, 90, 120, 3, None),
+    'edges': (64, 16, 16, 4, 'edges'),
+}
+
+
+def voxel_case(name):
+    N, H, W, seed, special = VOXEL_CASES[name]
+    xs, ys, ts, ps = voxel_oracle.synthetic_events(N, H, W, seed)
+    if special == 'dups':          # 300 events on one pixel
+        xs[100:400] = 7.0
+        ys[100:400] = 9.0
+    if special == 'edges':         # exact t0 / t_last duplicates, fractional coords, bin-centre times
+        ts[:4] = 0.0
+        ts[-4:] = ts[-1]
+        ts[10:15] = ts[-1] * np.array([0.25, 0.5, 0.75, 0.125, 0.999], dtype=np.float32)
+        ts = np.sort(ts)
+        xs[20:30] += np.float32(0.75)
+        ys[20:30] += np.float32(0.25)
+        xs = np.minimum(xs, np.float32(W - 0.01)).astype(np.float32)
+        ys = np.minimum(ys, np.float32(H - 0.01)).astype(np.float32)
+    return xs, ys, ts, ps, (H, W)
+
+
+def gen_voxels():
+    EU = ref_import.import_event_utils()
+    out = {}
+    for name in VOXEL_CASES:
+        xs, ys, ts, ps, size = voxel_case(name)
+        v = EU.events_to_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts),
+                                     torch.from_numpy(ps), 5, sensor_size=size)
+        out[name] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'voxel.npz'), **out)
+    print('voxel', {k: v.shape for k, v in out.items()})
+
+
+def gen_croper():
+    Croper = ref_import.import_croper()
+    res = {}
+    for (h, w) in [(180, 240), (260, 346), (480, 640), (720, 1280), (181, 243)]:
+        c = Croper(3)
+        c.update_params(w, h)
+        x = torch.arange(h * w, dtype=torch.float32).reshape(1, 1, h, w)
+        p = c.pad(x)
+        back = c.crop(p)
+        assert torch.equal(back, x)
+        res[f'{h}x{w}'] = dict(hc=c.height_crop_size, wc=c.width_crop_size,
+                               pad=[c.padding_left, c.padding_right, c.padding_top, c.padding_bottom],
+                               crop=[c.iy0, c.iy1, c.ix0, c.ix1],
+                               padded_shape=list(p.shape[-2:]),
+                               corner=[float(p[0, 0, c.padding_top, c.padding_left])])
+    with open(os.path.join(OUT, 'croper.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+    print('croper', res)
+
+
+if __name__ == '__main__':
+    assert ref_import.available(), 'needs /root/reference (build container only)'
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    gen_croper()
+    gen_voxels()
+    gen_blocks()
+    gen_e2e()
