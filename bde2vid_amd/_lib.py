@@ -1,0 +1,90 @@
+"""ctypes binding of libbde2vid.so (C ABI declared in include/bde2vid.h).
+
+The library is built in-tree by `make` / `__graft_entry__.build()`.  There is no
+fallback: if it is missing, `lib()` raises and nothing computes.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbde2vid.so')
+
+MAX_LEVELS = 8
+MAX_FRAMES = 8
+
+
+class BdeConfig(C.Structure):
+    _fields_ = [('num_bins', C.c_int32), ('basechannels', C.c_int32), ('num_encoders', C.c_int32),
+                ('ks', C.c_int32), ('num_heads', C.c_int32), ('frame_num', C.c_int32),
+                ('q_idx', C.c_int32), ('activation', C.c_int32),
+                ('depths', C.c_int32 * MAX_LEVELS), ('buffer_index', C.c_int32 * MAX_FRAMES)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/bde2vid.h one to one
+SIGNATURES = {
+    'bde_last_error': (C.c_char_p, []),
+    'bde_abi_version': (_I, []),
+    'bde_create': (_I, [C.POINTER(BdeConfig), _PP]),
+    'bde_destroy': (None, [_P]),
+    'bde_load_weight': (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
+    'bde_finalize_weights': (_I, [_P]),
+    'bde_packed_numel': (_L, [_P]),
+    'bde_packed_ptr': (_P, [_P]),
+    'bde_alloc_packed': (_I, [_P]),
+    'bde_forward': (_I, [_P, _PP, _I, _I, _I, _I, _PP, _P]),
+    'bde_get_intermediate': (_I, [_P, C.c_char_p, _P, _L, _P]),
+    'bde_voxelize': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
+    'bde_voxelize_batch': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
+    'bde_op_head': (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    'bde_op_recurrent_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'bde_op_encoder_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
+    'bde_op_decoder': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    'bde_op_pred': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'bde_op_dframe_attention': (_I, [_P, _I, _PP, _I, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). '
+                'bde2vid_amd has no CPU/PyTorch fallback.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the ABI and the binding drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int):
+    if status != 0:
+        msg = lib().bde_last_error()
+        raise RuntimeError(f'libbde2vid error {status}: {msg.decode("utf-8", "replace") if msg else "?"}')
+
+
+def make_config(cfg) -> BdeConfig:
+    """bde2vid_amd.config.GeneratorConfig -> C struct."""
+    cfg.validate()
+    c = BdeConfig()
+    c.num_bins, c.basechannels, c.num_encoders, c.ks = cfg.num_bins, cfg.basechannels, cfg.num_encoders, cfg.ks
+    c.num_heads, c.frame_num, c.q_idx = cfg.num_heads, cfg.frame_num, cfg.q_idx
+    c.activation = 1 if cfg.activation == 'Sigmoid' else 0
+    if cfg.num_encoders > MAX_LEVELS or cfg.frame_num > MAX_FRAMES:
+        raise ValueError('too many levels / buffer frames for the C ABI')
+    for i, d in enumerate(cfg.depths):
+        c.depths[i] = int(d)
+    for i, b in enumerate(cfg.buffer_index):
+        c.buffer_index[i] = int(b)
+    return c

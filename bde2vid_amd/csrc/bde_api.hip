@@ -1,0 +1,1124 @@
+// libbde2vid.so -- C ABI (include/bde2vid.h), weight packing and the forward schedule.
+//
+// The schedule restates BDE2VIDCrossscalePropogationV5.forward (V5.py:100-241) as a sequence of
+// launches of three hand-written gfx950 kernels (conv_mfma.h, attn.h, small element-wise ones):
+//   head conv (all T) -> per level { encoder conv x2 dirs (all T), gate x-part conv (all T),
+//   T recurrent ConvLSTM steps (both directions per launch), merge, temporal window attention
+//   (sequential in t, V5.py:154-169) } -> decoder (all T) -> predI + sigmoid (all T).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bde2vid.h"
+#include "attn.h"
+#include "common.h"
+#include "conv_mfma.h"
+#include "voxel.h"
+
+namespace bde {
+
+std::string& last_error_ref() {
+    static thread_local std::string e;
+    return e;
+}
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------
+// small element-wise kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add2_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                   float4* __restrict__ o, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 x = a[i], y = b[i];
+        o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+__global__ __launch_bounds__(256) void add2_tail_kernel(const float* a, const float* b, float* o, long beg, long n) {
+    long i = beg + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+static int add2(const float* a, const float* b, float* o, long n, hipStream_t s) {
+    long n4 = n / 4;
+    if (n4 > 0) {
+        long blocks = std::min<long>(cdivl(n4, 256), 2048);
+        hipLaunchKernelGGL(add2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)a, (const float4*)b,
+                           (float4*)o, n4);
+    }
+    if (n4 * 4 < n) hipLaunchKernelGGL(add2_tail_kernel, dim3(1), dim3(256), 0, s, a, b, o, n4 * 4, n);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+// predI (1x1 conv C->1) on (x + head) followed by the output activation (V5.py:195-197).
+__global__ __launch_bounds__(256) void pred_kernel(const float* __restrict__ x, const float* __restrict__ head,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ out, int C, long HW, long total, int sigmoid) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long n = i / HW, p = i - n * HW;
+        const float* xb = x + n * C * HW + p;
+        const float* hb = head ? head + n * C * HW + p : nullptr;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float v = xb[c * HW];
+            if (hb) v += hb[c * HW];
+            acc += w[c] * v;
+        }
+        acc += bias[0];
+        out[i] = sigmoid ? 1.f / (1.f + expf(-acc)) : acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// packed layers
+// ------------------------------------------------------------------------------------------
+enum Variant {
+    V_NONE = 0,
+    V_K5S1_M1N2, V_K5S1_M2N2, V_K5S2_M1N1, V_K5S2_M2N1, V_K5UP_M1N2, V_K5UP_M2N2,
+    V_K3S1_M1N2, V_K3S1_M2N2, V_K3S2_M1N1, V_K3S2_M2N1, V_K3UP_M1N2, V_K3UP_M2N2,
+    V_K3_LSTM,
+    V_K1_M1N2, V_K1_M2N2, V_K1SK_M1N1, V_K1SK_M2N1
+};
+
+struct VariantInfo { int KS, S, MT, CK; bool splitk; };
+static VariantInfo variant_info(Variant v) {
+    switch (v) {
+        case V_K5S1_M1N2: return {5, 1, 1, 8, false};
+        case V_K5S1_M2N2: return {5, 1, 2, 8, false};
+        case V_K5S2_M1N1: return {5, 2, 1, 8, false};
+        case V_K5S2_M2N1: return {5, 2, 2, 8, false};
+        case V_K5UP_M1N2: return {5, 1, 1, 8, false};
+        case V_K5UP_M2N2: return {5, 1, 2, 8, false};
+        case V_K3S1_M1N2: return {3, 1, 1, 8, false};
+        case V_K3S1_M2N2: return {3, 1, 2, 8, false};
+        case V_K3S2_M1N1: return {3, 2, 1, 8, false};
+        case V_K3S2_M2N1: return {3, 2, 2, 8, false};
+        case V_K3UP_M1N2: return {3, 1, 1, 8, false};
+        case V_K3UP_M2N2: return {3, 1, 2, 8, false};
+        case V_K3_LSTM:   return {3, 1, 4, 8, true};
+        case V_K1_M1N2:   return {1, 1, 1, 16, false};
+        case V_K1_M2N2:   return {1, 1, 2, 16, false};
+        case V_K1SK_M1N1: return {1, 1, 1, 16, true};
+        case V_K1SK_M2N1: return {1, 1, 2, 16, true};
+        default: return {0, 0, 0, 0, false};
+    }
+}
+
+static int launch_variant(Variant v, const ConvArgs& a, int G, hipStream_t s) {
+    switch (v) {
+        case V_K5S1_M1N2: return conv_launch_t<5, 1, 1, 2, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K5S1_M2N2: return conv_launch_t<5, 1, 2, 2, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K5S2_M1N1: return conv_launch_t<5, 2, 1, 1, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K5S2_M2N1: return conv_launch_t<5, 2, 2, 1, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K5UP_M1N2: return conv_launch_t<5, 1, 1, 2, 8, true, false, EPI_GENERIC>(a, G, s);
+        case V_K5UP_M2N2: return conv_launch_t<5, 1, 2, 2, 8, true, false, EPI_GENERIC>(a, G, s);
+        case V_K3S1_M1N2: return conv_launch_t<3, 1, 1, 2, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K3S1_M2N2: return conv_launch_t<3, 1, 2, 2, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K3S2_M1N1: return conv_launch_t<3, 2, 1, 1, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K3S2_M2N1: return conv_launch_t<3, 2, 2, 1, 8, false, false, EPI_GENERIC>(a, G, s);
+        case V_K3UP_M1N2: return conv_launch_t<3, 1, 1, 2, 8, true, false, EPI_GENERIC>(a, G, s);
+        case V_K3UP_M2N2: return conv_launch_t<3, 1, 2, 2, 8, true, false, EPI_GENERIC>(a, G, s);
+        case V_K3_LSTM:   return conv_launch_t<3, 1, 4, 1, 8, false, true, EPI_LSTM>(a, G, s);
+        case V_K1_M1N2:   return conv_launch_t<1, 1, 1, 2, 16, false, false, EPI_GENERIC>(a, G, s);
+        case V_K1_M2N2:   return conv_launch_t<1, 1, 2, 2, 16, false, false, EPI_GENERIC>(a, G, s);
+        case V_K1SK_M1N1: return conv_launch_t<1, 1, 1, 1, 16, false, true, EPI_GENERIC>(a, G, s);
+        case V_K1SK_M2N1: return conv_launch_t<1, 1, 2, 1, 16, false, true, EPI_GENERIC>(a, G, s);
+        default: return fail(BDE_ERR_STATE, "conv variant %d not built", (int)v);
+    }
+}
+
+// A dense host-side layer before packing: rows x (Cin*KS*KS), row-major [row][ci][ky][kx].
+struct DenseLayer {
+    int rows = 0, Cin = 0, KS = 1;
+    std::vector<float> w, bias, lnsum;   // lnsum empty unless the LayerNorm is folded
+};
+
+// One packed layer inside the device arena (offsets in floats).
+struct PackedLayer {
+    Variant v = V_NONE;
+    int Cin = 0, Cout = 0, KS = 1, nchunks = 0, ntiles = 0;
+    long w_off = -1, b_off = -1, s_off = -1;   // weights / bias / lnsum
+    long w_sz = 0;                              // floats of one group's packed weights
+    int G = 1;                                  // groups packed back to back (fwd, bwd)
+};
+
+struct Arena {
+    std::vector<float> host;
+    long alloc(long n) {
+        long off = (long)host.size();
+        long n4 = (n + 3) / 4 * 4;   // keep every segment 16-B aligned
+        host.resize(off + n4, 0.f);
+        return off;
+    }
+};
+
+// Pack rows into [tile][chunk][tap][pair][64] MFMA A-fragment order (conv_mfma.h):
+// lane l of fragment (tile, chunk, tap, pair) = W[row = tile*32 + (l&31)][ci = chunk*CK + 2*pair + (l>>5)][tap].
+// `rowmap[packed_row]` = source row or -1 (zero).
+static void pack_rows(const DenseLayer& d, const std::vector<int>& rowmap, int CK, int nchunks, float* dst) {
+    const int taps = d.KS * d.KS, pairs = CK / 2;
+    const int ntiles = (int)rowmap.size() / 32;
+    for (int tile = 0; tile < ntiles; ++tile)
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int pr = 0; pr < pairs; ++pr) {
+                    float* f = dst + ((((long)tile * nchunks + ch) * taps + tap) * pairs + pr) * 64;
+                    for (int l = 0; l < 64; ++l) {
+                        int row = rowmap[tile * 32 + (l & 31)];
+                        int ci = ch * CK + 2 * pr + (l >> 5);
+                        f[l] = (row >= 0 && ci < d.Cin) ? d.w[((long)row * d.Cin + ci) * taps + tap] : 0.f;
+                    }
+                }
+}
+
+static Variant pick_variant(int KS, int stride, bool up2, bool splitk, bool lstm, int Cout) {
+    const bool m2 = Cout > 32;
+    if (lstm) return V_K3_LSTM;
+    if (KS == 1) return splitk ? (m2 ? V_K1SK_M2N1 : V_K1SK_M1N1) : (m2 ? V_K1_M2N2 : V_K1_M1N2);
+    if (KS == 5) {
+        if (up2) return m2 ? V_K5UP_M2N2 : V_K5UP_M1N2;
+        if (stride == 2) return m2 ? V_K5S2_M2N1 : V_K5S2_M1N1;
+        return m2 ? V_K5S1_M2N2 : V_K5S1_M1N2;
+    }
+    if (KS == 3) {
+        if (up2) return m2 ? V_K3UP_M2N2 : V_K3UP_M1N2;
+        if (stride == 2) return m2 ? V_K3S2_M2N1 : V_K3S2_M1N1;
+        return m2 ? V_K3S1_M2N2 : V_K3S1_M1N2;
+    }
+    return V_NONE;
+}
+
+// Append G dense layers (same shape) to the arena as one grouped packed layer.
+static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, Variant v, bool lstm) {
+    const DenseLayer& d0 = *groups[0];
+    VariantInfo vi = variant_info(v);
+    PackedLayer pl;
+    pl.v = v;
+    pl.Cin = d0.Cin;
+    pl.Cout = d0.rows;
+    pl.KS = d0.KS;
+    pl.G = (int)groups.size();
+    pl.nchunks = cdiv(d0.Cin, vi.CK);
+    if (vi.splitk) pl.nchunks = cdiv(pl.nchunks, 4) * 4;
+    std::vector<int> rowmap;
+    if (lstm) {
+        // packed tile (cb*4 + gate) holds gate rows gate*Ch + cb*32 .. +32  (conv_mfma.h EPI_LSTM)
+        const int Ch = d0.rows / 4, ncb = cdiv(Ch, 32);
+        rowmap.assign((size_t)ncb * 4 * 32, -1);
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int gate = 0; gate < 4; ++gate)
+                for (int j = 0; j < 32; ++j)
+                    if (cb * 32 + j < Ch) rowmap[((size_t)cb * 4 + gate) * 32 + j] = gate * Ch + cb * 32 + j;
+    } else {
+        const int rows_pad = cdiv(d0.rows, 32 * vi.MT) * 32 * vi.MT;
+        rowmap.assign(rows_pad, -1);
+        for (int r = 0; r < d0.rows; ++r) rowmap[r] = r;
+    }
+    pl.ntiles = (int)rowmap.size() / 32;
+    pl.w_sz = (long)pl.ntiles * pl.nchunks * d0.KS * d0.KS * (vi.CK / 2) * 64;
+    pl.w_off = ar.alloc(pl.w_sz * pl.G);
+    pl.b_off = ar.alloc((long)d0.rows * pl.G);
+    const bool ln = !d0.lnsum.empty();
+    if (ln) pl.s_off = ar.alloc((long)d0.rows * pl.G);
+    for (int g = 0; g < pl.G; ++g) {
+        const DenseLayer& d = *groups[g];
+        pack_rows(d, rowmap, vi.CK, pl.nchunks, ar.host.data() + pl.w_off + g * pl.w_sz);
+        std::copy(d.bias.begin(), d.bias.end(), ar.host.begin() + pl.b_off + (long)g * d0.rows);
+        if (ln) std::copy(d.lnsum.begin(), d.lnsum.end(), ar.host.begin() + pl.s_off + (long)g * d0.rows);
+    }
+    return pl;
+}
+
+struct AttnBlock {
+    PackedLayer qkv, proj, fc1, fc2;
+    long kvpad_off = -1;    // [2C]
+    long bias_off = -1;     // [heads][D*49][49]
+};
+struct AttnLevel {
+    int depth = 0, C = 0;
+    std::vector<AttnBlock> blocks;
+    PackedLayer kvall;      // rows = depth*2C: K|V of every block for a non-query frame
+};
+
+struct Workspace {
+    int T = 0, B = 0, H = 0, W = 0;
+    std::vector<void*> allocs;
+    float* ev = nullptr;
+    float* head = nullptr;
+    float* out = nullptr;
+    std::vector<float*> xenc, gx, hseq, cst, merged, kvun, kvref, dec;
+    float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
+    void release() {
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+        T = B = H = W = 0;
+    }
+};
+
+}  // namespace bde
+
+using namespace bde;
+
+struct bde_model {
+    bde_config cfg;
+    int L = 0;
+    std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;
+    bool finalized = false;
+    Arena arena;
+    float* dev = nullptr;   // device image of the arena
+    long dev_numel = 0;
+    PackedLayer head, pred_dummy;
+    std::vector<PackedLayer> enc, gx, lstm, dec;   // enc/gx/lstm: G=2 (fwd,bwd)
+    std::vector<AttnLevel> attn;
+    long predw_off = -1, predb_off = -1;
+    Workspace ws;
+    int device = 0;
+
+    int cin(int l) const { return cfg.basechannels << l; }
+    int cout(int l) const { return cfg.basechannels << (l + 1); }
+    const float* P(long off) const { return dev + off; }
+};
+
+namespace bde {
+
+static const std::string GP = "generator.";
+
+static int get_raw(bde_model* m, const std::string& key, std::vector<int64_t> shape, const float** out) {
+    auto it = m->raw.find(GP + key);
+    if (it == m->raw.end()) return fail(BDE_ERR_STATE, "missing weight '%s%s'", GP.c_str(), key.c_str());
+    if (it->second.first != shape) {
+        std::string got, want;
+        for (auto v : it->second.first) got += std::to_string(v) + ",";
+        for (auto v : shape) want += std::to_string(v) + ",";
+        return fail(BDE_ERR_ARG, "weight '%s': shape [%s] but the config implies [%s]", key.c_str(), got.c_str(),
+                    want.c_str());
+    }
+    *out = it->second.second.data();
+    return BDE_OK;
+}
+
+static int dense_conv(bde_model* m, const std::string& wkey, const std::string& bkey, int rows, int cin_total,
+                      int ci_off, int cin, int ks, bool with_bias, DenseLayer* d) {
+    const float *w, *b;
+    BDE_TRY(get_raw(m, wkey, {rows, cin_total, ks, ks}, &w));
+    BDE_TRY(get_raw(m, bkey, {rows}, &b));
+    d->rows = rows;
+    d->Cin = cin;
+    d->KS = ks;
+    d->w.resize((size_t)rows * cin * ks * ks);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ks * ks; ++t)
+                d->w[((size_t)r * cin + c) * ks * ks + t] = w[((size_t)r * cin_total + ci_off + c) * ks * ks + t];
+    d->bias.assign(rows, 0.f);
+    if (with_bias) std::copy(b, b + rows, d->bias.begin());
+    return BDE_OK;
+}
+
+// Linear(LayerNorm(x)) = rstd * (W' x - mu * s) + b'  with  W' = W diag(gamma), s = W' 1, b' = W beta + b.
+// `scale` multiplies the whole output (query scale, DTransformer.py:192).
+static void fold_ln_rows(const float* W, const float* b, const float* gamma, const float* beta, int rows, int C,
+                         float scale, DenseLayer* d, int row_off) {
+    for (int r = 0; r < rows; ++r) {
+        double s = 0.0, bb = b[r];
+        for (int c = 0; c < C; ++c) {
+            float wf = W[(size_t)r * C + c] * gamma[c];
+            d->w[(size_t)(row_off + r) * C + c] = wf * scale;
+            s += (double)wf;
+            bb += (double)W[(size_t)r * C + c] * (double)beta[c];
+        }
+        d->lnsum[row_off + r] = (float)(s * scale);
+        d->bias[row_off + r] = (float)(bb * scale);
+    }
+}
+
+static int build_packed(bde_model* m) {
+    const bde_config& c = m->cfg;
+    const int L = c.num_encoders, ks = c.ks, bc = c.basechannels;
+    Arena& ar = m->arena;
+    ar.host.clear();
+    m->enc.assign(L, PackedLayer());
+    m->gx.assign(L, PackedLayer());
+    m->lstm.assign(L, PackedLayer());
+    m->dec.assign(L, PackedLayer());
+    m->attn.assign(L, AttnLevel());
+    {
+        DenseLayer d;
+        BDE_TRY(dense_conv(m, "head.conv2d.weight", "head.conv2d.bias", bc, c.num_bins, 0, c.num_bins, ks, true, &d));
+        m->head = pack_layer(ar, {&d}, pick_variant(ks, 1, false, false, false, bc), false);
+    }
+    const char* dirs[2] = {"forward_encoder", "backward_encoder"};
+    for (int l = 0; l < L; ++l) {
+        const int ci = m->cin(l), co = m->cout(l);
+        DenseLayer e[2], gxd[2], gh[2];
+        for (int d = 0; d < 2; ++d) {
+            std::string p = std::string(dirs[d]) + "." + std::to_string(l) + ".";
+            BDE_TRY(dense_conv(m, p + "conv.conv2d.weight", p + "conv.conv2d.bias", co, ci, 0, ci, ks, true, &e[d]));
+            // Gates weight in-channel order is [x | h] (submodules.py:316)
+            BDE_TRY(dense_conv(m, p + "recurrent_block.Gates.weight", p + "recurrent_block.Gates.bias", 4 * co, 2 * co, 0,
+                               co, 3, true, &gxd[d]));
+            BDE_TRY(dense_conv(m, p + "recurrent_block.Gates.weight", p + "recurrent_block.Gates.bias", 4 * co, 2 * co, co,
+                               co, 3, false, &gh[d]));
+        }
+        m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, pick_variant(ks, 2, false, false, false, co), false);
+        m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, pick_variant(3, 1, false, false, false, 4 * co), false);
+        m->lstm[l] = pack_layer(ar, {&gh[0], &gh[1]}, V_K3_LSTM, true);
+    }
+    const int D = c.frame_num, heads = c.num_heads;
+    const int tbl_rows = (2 * D - 1) * 13 * 13;
+    for (int l = 0; l < L; ++l) {
+        AttnLevel& al = m->attn[l];
+        al.depth = c.depths[l];
+        al.C = m->cout(l);
+        if (al.depth == 0) continue;
+        const int C = al.C, hid = 4 * C, hd = C / heads;
+        const float scale = 1.0f / std::sqrt((float)hd);
+        DenseLayer kvall;
+        kvall.rows = al.depth * 2 * C;
+        kvall.Cin = C;
+        kvall.KS = 1;
+        kvall.w.resize((size_t)kvall.rows * C);
+        kvall.bias.resize(kvall.rows);
+        kvall.lnsum.resize(kvall.rows);
+        al.blocks.resize(al.depth);
+        for (int i = 0; i < al.depth; ++i) {
+            AttnBlock& ab = al.blocks[i];
+            std::string p = "feat_attns." + std::to_string(l) + ".blocks." + std::to_string(i) + ".";
+            const float *tbl, *gq, *bq, *gkv, *bkv, *wq, *biq, *wkv, *bikv, *wp, *bp, *g2, *b2, *w1, *b1, *w2, *b2b;
+            BDE_TRY(get_raw(m, p + "attn.relative_position_bias_table", {tbl_rows, heads}, &tbl));
+            BDE_TRY(get_raw(m, p + "attn.norm_q.weight", {C}, &gq));
+            BDE_TRY(get_raw(m, p + "attn.norm_q.bias", {C}, &bq));
+            BDE_TRY(get_raw(m, p + "attn.norm_kv.weight", {C}, &gkv));
+            BDE_TRY(get_raw(m, p + "attn.norm_kv.bias", {C}, &bkv));
+            BDE_TRY(get_raw(m, p + "attn.q.weight", {C, C}, &wq));
+            BDE_TRY(get_raw(m, p + "attn.q.bias", {C}, &biq));
+            BDE_TRY(get_raw(m, p + "attn.kv.weight", {2 * C, C}, &wkv));
+            BDE_TRY(get_raw(m, p + "attn.kv.bias", {2 * C}, &bikv));
+            BDE_TRY(get_raw(m, p + "attn.proj.weight", {C, C}, &wp));
+            BDE_TRY(get_raw(m, p + "attn.proj.bias", {C}, &bp));
+            BDE_TRY(get_raw(m, p + "norm2.weight", {C}, &g2));
+            BDE_TRY(get_raw(m, p + "norm2.bias", {C}, &b2));
+            BDE_TRY(get_raw(m, p + "mlp.fc1.weight", {hid, C}, &w1));
+            BDE_TRY(get_raw(m, p + "mlp.fc1.bias", {hid}, &b1));
+            BDE_TRY(get_raw(m, p + "mlp.fc2.weight", {C, hid}, &w2));
+            BDE_TRY(get_raw(m, p + "mlp.fc2.bias", {C}, &b2b));
+            // q | k | v stacked: one GEMM on the query frame; the three LayerNorms share (mu, rstd)
+            DenseLayer qkv;
+            qkv.rows = 3 * C;
+            qkv.Cin = C;
+            qkv.KS = 1;
+            qkv.w.resize((size_t)3 * C * C);
+            qkv.bias.resize(3 * C);
+            qkv.lnsum.resize(3 * C);
+            fold_ln_rows(wq, biq, gq, bq, C, C, scale, &qkv, 0);
+            fold_ln_rows(wkv, bikv, gkv, bkv, 2 * C, C, 1.f, &qkv, C);
+            fold_ln_rows(wkv, bikv, gkv, bkv, 2 * C, C, 1.f, &kvall, i * 2 * C);
+            ab.qkv = pack_layer(ar, {&qkv}, pick_variant(1, 1, false, true, false, 3 * C), false);
+            // K|V of an all-zero token: LayerNorm(0) = beta  ->  W beta + b  (DTransformer.py:183-190)
+            ab.kvpad_off = ar.alloc(2 * C);
+            std::copy(qkv.bias.begin() + C, qkv.bias.end(), ar.host.begin() + ab.kvpad_off);
+            // dense relative-position bias of the query frame's rows, transposed to [head][n][m]
+            // (DTransformer.py:139-153,195-199): index = ((dd+D-1)*13 + (dh+6))*13 + (dw+6)
+            const int N = D * 49;
+            ab.bias_off = ar.alloc((long)heads * N * 49);
+            float* bt = ar.host.data() + ab.bias_off;
+            for (int mq = 0; mq < 49; ++mq) {
+                int qh = mq / 7, qw = mq % 7;
+                for (int n = 0; n < N; ++n) {
+                    int kd = n / 49, kh = (n % 49) / 7, kw = n % 7;
+                    int idx = ((c.q_idx - kd + D - 1) * 13 + (qh - kh + 6)) * 13 + (qw - kw + 6);
+                    for (int h = 0; h < heads; ++h) bt[((long)h * N + n) * 49 + mq] = tbl[(long)idx * heads + h];
+                }
+            }
+            DenseLayer proj;
+            proj.rows = C; proj.Cin = C; proj.KS = 1;
+            proj.w.assign(wp, wp + (size_t)C * C);
+            proj.bias.assign(bp, bp + C);
+            ab.proj = pack_layer(ar, {&proj}, pick_variant(1, 1, false, true, false, C), false);
+            DenseLayer fc1;
+            fc1.rows = hid; fc1.Cin = C; fc1.KS = 1;
+            fc1.w.resize((size_t)hid * C);
+            fc1.bias.resize(hid);
+            fc1.lnsum.resize(hid);
+            fold_ln_rows(w1, b1, g2, b2, hid, C, 1.f, &fc1, 0);
+            ab.fc1 = pack_layer(ar, {&fc1}, pick_variant(1, 1, false, true, false, hid), false);
+            DenseLayer fc2;
+            fc2.rows = C; fc2.Cin = hid; fc2.KS = 1;
+            fc2.w.assign(w2, w2 + (size_t)C * hid);
+            fc2.bias.assign(b2b, b2b + C);
+            ab.fc2 = pack_layer(ar, {&fc2}, pick_variant(1, 1, false, true, false, C), false);
+        }
+        al.kvall = pack_layer(ar, {&kvall}, pick_variant(1, 1, false, false, false, kvall.rows), false);
+    }
+    for (int j = 0; j < L; ++j) {
+        const int cin = m->cout(L - 1 - j), cout = m->cin(L - 1 - j);
+        DenseLayer d;
+        std::string p = "decoders." + std::to_string(j) + ".1.conv2d.";
+        BDE_TRY(dense_conv(m, p + "weight", p + "bias", cout, cin, 0, cin, ks, true, &d));
+        m->dec[j] = pack_layer(ar, {&d}, pick_variant(ks, 1, true, false, false, cout), false);
+    }
+    {
+        const float *w, *b;
+        BDE_TRY(get_raw(m, "predI.1.weight", {1, bc, 1, 1}, &w));
+        BDE_TRY(get_raw(m, "predI.1.bias", {1}, &b));
+        m->predw_off = ar.alloc(bc);
+        std::copy(w, w + bc, ar.host.begin() + m->predw_off);
+        m->predb_off = ar.alloc(1);
+        ar.host[m->predb_off] = b[0];
+    }
+    return BDE_OK;
+}
+
+static int upload(bde_model* m) {
+    if (m->dev) (void)hipFree(m->dev);
+    m->dev = nullptr;
+    m->dev_numel = (long)m->arena.host.size();
+    BDE_HIP(hipMalloc((void**)&m->dev, sizeof(float) * m->dev_numel));
+    BDE_HIP(hipMemcpy(m->dev, m->arena.host.data(), sizeof(float) * m->dev_numel, hipMemcpyHostToDevice));
+    std::vector<float>().swap(m->arena.host);
+    m->raw.clear();
+    m->finalized = true;
+    return BDE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// conv launch helper
+// ------------------------------------------------------------------------------------------
+struct ConvCall {
+    const PackedLayer* pl = nullptr;
+    const float* in = nullptr;
+    const float* in2 = nullptr;
+    float* out = nullptr;
+    const float* res1 = nullptr;
+    const float* res2 = nullptr;
+    int N = 1, Hs = 0, Ws = 0;   // stored input dims
+    bool up2 = false;
+    int stride = 1;
+    int act = ACT_NONE;
+    long in_gs = 0, out_gs = 0;  // group strides (0 = shared input)
+    int mask_w = 0, mask_pt = 0, mask_pl = 0;
+    int cout_rows = -1;          // override (kvall uses all rows)
+};
+
+static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
+    const PackedLayer& pl = *cc.pl;
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = cc.in;
+    a.in2 = cc.in2;
+    a.wpk = m->P(pl.w_off);
+    a.bias = m->P(pl.b_off);
+    a.lnsum = pl.s_off >= 0 ? m->P(pl.s_off) : nullptr;
+    a.res1 = cc.res1;
+    a.res2 = cc.res2;
+    a.out = cc.out;
+    a.N = cc.N;
+    a.Cin = pl.Cin;
+    a.Hs = cc.Hs;
+    a.Ws = cc.Ws;
+    a.Hin = cc.up2 ? 2 * cc.Hs : cc.Hs;
+    a.Win = cc.up2 ? 2 * cc.Ws : cc.Ws;
+    a.Cout = pl.Cout;
+    const int pad = pl.KS / 2;
+    a.Ho = (a.Hin + 2 * pad - pl.KS) / cc.stride + 1;
+    a.Wo = (a.Win + 2 * pad - pl.KS) / cc.stride + 1;
+    a.nchunks = pl.nchunks;
+    a.act = cc.act;
+    a.mask_w = cc.mask_w;
+    a.mask_pt = cc.mask_pt;
+    a.mask_pl = cc.mask_pl;
+    const long in_fs = (long)pl.Cin * cc.Hs * cc.Ws, out_fs = (long)pl.Cout * a.Ho * a.Wo;
+    a.in_ns = a.in2_ns = in_fs;
+    a.out_ns = a.res1_ns = a.res2_ns = out_fs;
+    a.in_gs = cc.in_gs;
+    a.in2_gs = cc.in_gs;
+    a.out_gs = cc.out_gs;
+    a.res1_gs = a.res2_gs = cc.out_gs;
+    a.w_gs = pl.w_sz;
+    a.bias_gs = pl.Cout;
+    return launch_variant(pl.v, a, pl.G, s);
+}
+
+// 1x1 conv over flattened [C][HW] planes
+static int run_pw(const bde_model* m, const PackedLayer* pl, const float* in, float* out, int N, long HW, int act,
+                  const float* res1, const float* res2, int mask_w, int mask_pt, int mask_pl, hipStream_t s) {
+    ConvCall cc;
+    cc.pl = pl;
+    cc.in = in;
+    cc.out = out;
+    cc.N = N;
+    cc.Hs = 1;
+    cc.Ws = (int)HW;
+    cc.act = act;
+    cc.res1 = res1;
+    cc.res2 = res2;
+    cc.mask_w = mask_w;
+    cc.mask_pt = mask_pt;
+    cc.mask_pl = mask_pl;
+    return run_conv(m, cc, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+static int ws_alloc(Workspace& ws, float** p, long numel) {
+    void* q = nullptr;
+    BDE_HIP(hipMalloc(&q, sizeof(float) * (size_t)std::max<long>(numel, 4)));
+    ws.allocs.push_back(q);
+    *p = (float*)q;
+    return BDE_OK;
+}
+
+static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
+    Workspace& ws = m->ws;
+    if (ws.T == T && ws.B == B && ws.H == H && ws.W == W) return BDE_OK;
+    ws.release();
+    const bde_config& c = m->cfg;
+    const int L = c.num_encoders;
+    const long TB = (long)T * B;
+    BDE_TRY(ws_alloc(ws, &ws.ev, TB * c.num_bins * H * W));
+    BDE_TRY(ws_alloc(ws, &ws.head, TB * c.basechannels * H * W));
+    BDE_TRY(ws_alloc(ws, &ws.out, TB * H * W));
+    ws.xenc.assign(L, nullptr); ws.gx.assign(L, nullptr); ws.hseq.assign(L, nullptr); ws.cst.assign(L, nullptr);
+    ws.merged.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr);
+    long max_attn = 0;
+    for (int l = 0; l < L; ++l) {
+        const long C = m->cout(l), hw = (long)(H >> (l + 1)) * (W >> (l + 1));
+        BDE_TRY(ws_alloc(ws, &ws.xenc[l], 2 * TB * C * hw));
+        BDE_TRY(ws_alloc(ws, &ws.gx[l], 2 * TB * 4 * C * hw));
+        BDE_TRY(ws_alloc(ws, &ws.hseq[l], 2 * TB * C * hw));
+        BDE_TRY(ws_alloc(ws, &ws.cst[l], 2 * (long)B * C * hw));
+        BDE_TRY(ws_alloc(ws, &ws.merged[l], TB * C * hw));
+        if (c.depths[l] > 0) {
+            BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
+            BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
+            max_attn = std::max(max_attn, (long)B * C * hw);
+        }
+        const int j = L - 1 - l;   // decoder j writes the map of level (L-1-j)'s input resolution
+        BDE_TRY(ws_alloc(ws, &ws.dec[j], TB * m->cin(l) * (long)(H >> l) * (W >> l)));
+    }
+    if (max_attn > 0) {
+        BDE_TRY(ws_alloc(ws, &ws.qkv, 3 * max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.ao, max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.x1, max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.hid, 4 * max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.xa, max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.xb, max_attn));
+    }
+    ws.T = T; ws.B = B; ws.H = H; ws.W = W;
+    return BDE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stages
+// ------------------------------------------------------------------------------------------
+// RecurrentConv sweep of one level for both directions (V5.py:122-135; submodules.py:191-195).
+//   in: [TB][Cin][H][W].  Results: ws.hseq[l] = [2][TB][C][h][w]; ws.cst[l] final cell states.
+// dir_mask: bit0 forward, bit1 backward (the op-level test runs a single direction).
+static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int B, int H, int W, hipStream_t s) {
+    Workspace& ws = m->ws;
+    const int C = m->cout(l), h = H / 2, w = W / 2;
+    const long TB = (long)T * B, hw = (long)h * w;
+    // encoder conv, both directions read the same sequence (V5.py:124-130)
+    ConvCall e;
+    e.pl = &m->enc[l];
+    e.in = in;
+    e.out = ws.xenc[l];
+    e.N = (int)TB;
+    e.Hs = H;
+    e.Ws = W;
+    e.stride = 2;
+    e.act = ACT_RELU;
+    e.in_gs = 0;
+    e.out_gs = TB * C * hw;
+    BDE_TRY(run_conv(m, e, s));
+    // x-part of the gates for every t (non-recurrent): gx = conv3x3(x; W[:, :C]) + bias
+    ConvCall gxc;
+    gxc.pl = &m->gx[l];
+    gxc.in = ws.xenc[l];
+    gxc.out = ws.gx[l];
+    gxc.N = (int)TB;
+    gxc.Hs = h;
+    gxc.Ws = w;
+    gxc.in_gs = TB * C * hw;
+    gxc.out_gs = TB * 4 * C * hw;
+    BDE_TRY(run_conv(m, gxc, s));
+    // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
+    const PackedLayer& pl = m->lstm[l];
+    float* hs = ws.hseq[l];
+    const long dstride = TB * C * hw;          // direction stride inside hseq
+    const long fs = (long)B * C * hw;          // one time step (B frames)
+    for (int st = 0; st < T; ++st) {
+        const int tf = st, tb = T - 1 - st;
+        ConvArgs a;
+        memset(&a, 0, sizeof a);
+        a.first = (st == 0);
+        const float* hprev_f = hs + (long)(tf - 1) * fs;               // unused when first
+        const float* hprev_b = hs + dstride + (long)(tb + 1) * fs;
+        if (a.first) { hprev_f = hs; hprev_b = hs; }
+        a.in = hprev_f;
+        a.in_gs = hprev_b - hprev_f;
+        a.in_ns = (long)C * hw;
+        a.wpk = m->P(pl.w_off);
+        a.w_gs = pl.w_sz;
+        a.bias = m->P(pl.b_off);
+        a.out = hs + (long)tf * fs;
+        a.out_gs = (hs + dstride + (long)tb * fs) - a.out;
+        a.out_ns = (long)C * hw;
+        a.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
+        a.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - a.gx;
+        a.gx_ns = (long)4 * C * hw;
+        a.cstate = ws.cst[l];
+        a.c_gs = (long)B * C * hw;
+        a.c_ns = (long)C * hw;
+        a.N = B;
+        a.Cin = C;
+        a.Hin = a.Hs = h;
+        a.Win = a.Ws = w;
+        a.Cout = 4 * C;
+        a.Ho = h;
+        a.Wo = w;
+        a.nchunks = pl.nchunks;
+        BDE_TRY(launch_variant(pl.v, a, 2, s));
+    }
+    return BDE_OK;
+}
+
+// DFrameAttention + in-place refinement for one target frame (V5.py:154-169; DTransformer.py:376-389).
+//   xq      : query frame [B][C][HW] (slot q_idx)
+//   kvslot  : per slot, base of the [B][depth*2C][HW] K|V stack of that frame (nullptr = zero frame);
+//             ignored for slot q_idx
+//   addres  : tensor added to the result (merged[t], V5.py:166) or nullptr
+//   out     : [B][C][HW]
+static int run_attention_frame(bde_model* m, int l, const float* xq, const float* const* kvslot, const float* addres,
+                               float* out, int B, int H, int W, int blk0, int nblk, hipStream_t s) {
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->ws;
+    const AttnLevel& al = m->attn[l];
+    const int C = al.C, D = c.frame_num;
+    const long HW = (long)H * W;
+    const int ph = (7 - H % 7) % 7, pw = (7 - W % 7) % 7;   // DTransformer.py:260-263
+    const int pt = ph / 2, plft = pw / 2;
+    const int Hp = H + ph, Wp = W + pw;
+    const float* x = xq;
+    for (int i = blk0; i < blk0 + nblk; ++i) {
+        const AttnBlock& ab = al.blocks[i];
+        const bool dil = (i % 2) == 1;                       // DTransformer.py:362
+        const bool last = (i == blk0 + nblk - 1);
+        // q | k | v of the current x
+        BDE_TRY(run_pw(m, &ab.qkv, x, ws.qkv, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+        AttnArgs a;
+        memset(&a, 0, sizeof a);
+        a.q = ws.qkv;
+        a.q_bs = 3 * C * HW;
+        for (int d = 0; d < D; ++d) {
+            if (d == c.q_idx) {
+                a.kv[d] = ws.qkv + (long)C * HW;
+                a.kv_bs[d] = 3 * C * HW;
+            } else if (kvslot[d]) {
+                a.kv[d] = kvslot[d] + (long)i * 2 * C * HW;
+                a.kv_bs[d] = (long)al.depth * 2 * C * HW;
+            } else {
+                a.kv[d] = nullptr;
+            }
+            a.v_off[d] = (long)C * HW;
+        }
+        a.kvpad = m->P(ab.kvpad_off);
+        a.biasT = m->P(ab.bias_off);
+        a.out = ws.ao;
+        a.out_bs = C * HW;
+        a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
+        a.pt = pt; a.pl = plft; a.nWw = Wp / 7; a.dilated = dil ? 1 : 0;
+        BDE_TRY(attn_launch(a, B, s));
+        // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only)
+        BDE_TRY(run_pw(m, &ab.proj, ws.ao, ws.x1, B, HW, ACT_NONE, x, nullptr, dil ? W : 0, pt, plft, s));
+        // x2 = x1 + fc2(GELU(fc1(LN(x1))))  (+ merged[t] after the last block)
+        BDE_TRY(run_pw(m, &ab.fc1, ws.x1, ws.hid, B, HW, ACT_GELU, nullptr, nullptr, 0, 0, 0, s));
+        float* dst = last ? out : (x == ws.xa ? ws.xb : ws.xa);
+        BDE_TRY(run_pw(m, &ab.fc2, ws.hid, dst, B, HW, ACT_NONE, ws.x1, last ? addres : nullptr, 0, 0, 0, s));
+        x = dst;
+    }
+    return BDE_OK;
+}
+
+static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, hipStream_t s) {
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->ws;
+    const AttnLevel& al = m->attn[l];
+    const int C = al.C, D = c.frame_num;
+    const long HW = (long)H * W, fs = (long)B * C * HW;
+    const long kvfs = (long)B * al.depth * 2 * C * HW;
+    bool need_un = false, need_ref = false;
+    for (int d = 0; d < D; ++d) {
+        if (d == c.q_idx) continue;
+        if (c.buffer_index[d] >= 0) need_un = true; else need_ref = true;
+    }
+    // K|V of every block for the still-unrefined frames, all T at once
+    if (need_un)
+        BDE_TRY(run_pw(m, &al.kvall, ws.merged[l], ws.kvun[l], T * B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+    for (int t = 0; t < T; ++t) {
+        const float* kvslot[BDE_MAX_FRAMES];
+        for (int d = 0; d < D; ++d) {
+            const int f = t + c.buffer_index[d];
+            if (d == c.q_idx || f < 0 || f >= T) kvslot[d] = nullptr;
+            else if (f < t) kvslot[d] = ws.kvref[l] + (long)f * kvfs;      // refined (V5.py:166-169)
+            else kvslot[d] = ws.kvun[l] + (long)f * kvfs;
+        }
+        float* mt = ws.merged[l] + (long)t * fs;
+        BDE_TRY(run_attention_frame(m, l, mt, kvslot, mt, mt, B, H, W, 0, al.depth, s));
+        if (need_ref && t + 1 < T)
+            BDE_TRY(run_pw(m, &al.kvall, mt, ws.kvref[l] + (long)t * kvfs, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+    }
+    return BDE_OK;
+}
+
+static int check_dims(const bde_model* m, int T, int B, int H, int W) {
+    const bde_config& c = m->cfg;
+    BDE_REQUIRE(m->finalized, "weights are not finalized");
+    BDE_REQUIRE(T >= 1 && B >= 1, "T=%d B=%d", T, B);
+    const int mult = 1 << c.num_encoders;
+    BDE_REQUIRE(H > 0 && W > 0 && H % mult == 0 && W % mult == 0, "H=%d W=%d must be multiples of %d", H, W, mult);
+    for (int l = 0; l < c.num_encoders; ++l)
+        if (c.depths[l] > 0)
+            BDE_REQUIRE((H >> (l + 1)) >= 7 && (W >> (l + 1)) >= 7,
+                        "feature map %dx%d at attention level %d is smaller than the 7x7 window (the reference "
+                        "raises there too)", H >> (l + 1), W >> (l + 1), l);
+    return BDE_OK;
+}
+
+static int forward_impl(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
+                        hipStream_t s) {
+    BDE_TRY(check_dims(m, T, B, H, W));
+    BDE_TRY(ensure_workspace(m, T, B, H, W));
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->ws;
+    const int L = c.num_encoders;
+    const long TB = (long)T * B;
+    const long ev_fs = (long)B * c.num_bins * H * W, img_fs = (long)B * H * W;
+    for (int t = 0; t < T; ++t)
+        BDE_HIP(hipMemcpyAsync(ws.ev + t * ev_fs, events[t], sizeof(float) * ev_fs, hipMemcpyDeviceToDevice, s));
+    // A. head (V5.py:116)
+    ConvCall hc;
+    hc.pl = &m->head;
+    hc.in = ws.ev;
+    hc.out = ws.head;
+    hc.N = (int)TB;
+    hc.Hs = H;
+    hc.Ws = W;
+    hc.act = ACT_RELU;
+    BDE_TRY(run_conv(m, hc, s));
+    // B. levels (V5.py:119-172)
+    const float* target = ws.head;
+    for (int l = 0; l < L; ++l) {
+        const int Hl = H >> l, Wl = W >> l, h = Hl / 2, w = Wl / 2, C = m->cout(l);
+        BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s));
+        const long n = TB * C * h * w;
+        BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s));   // V5.py:137-147
+        if (c.depths[l] > 0) BDE_TRY(run_attention_level(m, l, T, B, h, w, s));
+        target = ws.merged[l];
+    }
+    // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x)
+    const float* x = ws.merged[L - 1];
+    for (int j = 0; j < L; ++j) {
+        const int l = L - 1 - j;
+        ConvCall d;
+        d.pl = &m->dec[j];
+        d.in = x;
+        d.in2 = ws.merged[l];
+        d.out = ws.dec[j];
+        d.N = (int)TB;
+        d.Hs = H >> (l + 1);
+        d.Ws = W >> (l + 1);
+        d.up2 = true;
+        d.act = ACT_RELU6;
+        BDE_TRY(run_conv(m, d, s));
+        x = ws.dec[j];
+    }
+    {
+        const long total = TB * H * W;
+        long blocks = std::min<long>(cdivl(total, 256), 4096);
+        hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ws.head, m->P(m->predw_off),
+                           m->P(m->predb_off), ws.out, c.basechannels, (long)H * W, total, c.activation);
+        BDE_HIP(hipGetLastError());
+    }
+    for (int t = 0; t < T; ++t)
+        BDE_HIP(hipMemcpyAsync(images[t], ws.out + t * img_fs, sizeof(float) * img_fs, hipMemcpyDeviceToDevice, s));
+    return BDE_OK;
+}
+
+static int validate_config(const bde_config* c) {
+    BDE_REQUIRE(c != nullptr, "null config");
+    BDE_REQUIRE(c->num_encoders >= 1 && c->num_encoders <= BDE_MAX_LEVELS, "num_encoders=%d", c->num_encoders);
+    BDE_REQUIRE(c->num_bins >= 1 && c->basechannels >= 1, "num_bins=%d basechannels=%d", c->num_bins, c->basechannels);
+    BDE_REQUIRE(c->ks == 3 || c->ks == 5, "ks=%d (3 or 5)", c->ks);
+    BDE_REQUIRE(c->frame_num >= 1 && c->frame_num <= BDE_MAX_FRAMES, "frame_num=%d", c->frame_num);
+    BDE_REQUIRE(c->q_idx >= 0 && c->q_idx < c->frame_num, "q_idx=%d", c->q_idx);
+    BDE_REQUIRE(c->buffer_index[c->q_idx] == 0, "buffer_index[q_idx] must be 0 (the query frame is the current frame)");
+    BDE_REQUIRE(c->activation == 0 || c->activation == 1, "activation=%d", c->activation);
+    BDE_REQUIRE(c->depths[c->num_encoders - 1] > 0, "depths[-1]==0 (ResidualBlockNoBN bottleneck) is not built");
+    for (int l = 0; l < c->num_encoders; ++l) {
+        BDE_REQUIRE(c->depths[l] >= 0, "depths[%d]=%d", l, c->depths[l]);
+        if (c->depths[l] > 0) {
+            const int C = c->basechannels << (l + 1);
+            BDE_REQUIRE(c->num_heads >= 1 && C % c->num_heads == 0, "C=%d not divisible by %d heads", C, c->num_heads);
+            const int hd = C / c->num_heads;
+            BDE_REQUIRE(hd == 1 || hd == 2 || hd == 4 || hd == 8 || hd == 16 || hd == 32, "head_dim=%d not built", hd);
+        }
+    }
+    return BDE_OK;
+}
+
+}  // namespace bde
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char* bde_last_error(void) { return last_error_ref().c_str(); }
+int bde_abi_version(void) { return 1; }
+
+int bde_create(const bde_config* cfg, bde_model** out) {
+    BDE_REQUIRE(out != nullptr, "null out");
+    BDE_TRY(validate_config(cfg));
+    bde_model* m = new bde_model();
+    m->cfg = *cfg;
+    m->L = cfg->num_encoders;
+    *out = m;
+    return BDE_OK;
+}
+
+void bde_destroy(bde_model* m) {
+    if (!m) return;
+    m->ws.release();
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+}
+
+int bde_load_weight(bde_model* m, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+    BDE_REQUIRE(m && key && data && shape && ndim >= 1 && ndim <= 8, "bad argument");
+    int64_t n = 1;
+    std::vector<int64_t> sh(shape, shape + ndim);
+    for (auto v : sh) {
+        BDE_REQUIRE(v >= 1, "weight '%s' has a non-positive dimension", key);
+        n *= v;
+    }
+    m->raw[key] = {sh, std::vector<float>(data, data + n)};
+    m->finalized = false;
+    return BDE_OK;
+}
+
+int bde_finalize_weights(bde_model* m) {
+    BDE_REQUIRE(m != nullptr, "null model");
+    BDE_HIP(hipGetDevice(&m->device));
+    BDE_TRY(build_packed(m));
+    return upload(m);
+}
+
+int bde_alloc_packed(bde_model* m) {
+    // Same layout as bde_finalize_weights but with zero content (to be overwritten by a broadcast):
+    // synthesise zero tensors for every key the packer asks for.
+    BDE_REQUIRE(m != nullptr, "null model");
+    const bde_config& c = m->cfg;
+    auto put = [&](const std::string& k, std::vector<int64_t> sh) {
+        int64_t n = 1;
+        for (auto v : sh) n *= v;
+        m->raw[GP + k] = {sh, std::vector<float>((size_t)n, 0.f)};
+    };
+    const int L = c.num_encoders, ks = c.ks, bc = c.basechannels;
+    put("head.conv2d.weight", {bc, c.num_bins, ks, ks});
+    put("head.conv2d.bias", {bc});
+    const char* dirs[2] = {"forward_encoder", "backward_encoder"};
+    for (int d = 0; d < 2; ++d)
+        for (int l = 0; l < L; ++l) {
+            std::string p = std::string(dirs[d]) + "." + std::to_string(l) + ".";
+            const int ci = bc << l, co = bc << (l + 1);
+            put(p + "conv.conv2d.weight", {co, ci, ks, ks});
+            put(p + "conv.conv2d.bias", {co});
+            put(p + "recurrent_block.Gates.weight", {4 * co, 2 * co, 3, 3});
+            put(p + "recurrent_block.Gates.bias", {4 * co});
+        }
+    const int tbl = (2 * c.frame_num - 1) * 169;
+    for (int l = 0; l < L; ++l) {
+        const int C = bc << (l + 1);
+        for (int i = 0; i < c.depths[l]; ++i) {
+            std::string p = "feat_attns." + std::to_string(l) + ".blocks." + std::to_string(i) + ".";
+            put(p + "attn.relative_position_bias_table", {tbl, c.num_heads});
+            put(p + "attn.norm_q.weight", {C}); put(p + "attn.norm_q.bias", {C});
+            put(p + "attn.norm_kv.weight", {C}); put(p + "attn.norm_kv.bias", {C});
+            put(p + "attn.q.weight", {C, C}); put(p + "attn.q.bias", {C});
+            put(p + "attn.kv.weight", {2 * C, C}); put(p + "attn.kv.bias", {2 * C});
+            put(p + "attn.proj.weight", {C, C}); put(p + "attn.proj.bias", {C});
+            put(p + "norm2.weight", {C}); put(p + "norm2.bias", {C});
+            put(p + "mlp.fc1.weight", {4 * C, C}); put(p + "mlp.fc1.bias", {4 * C});
+            put(p + "mlp.fc2.weight", {C, 4 * C}); put(p + "mlp.fc2.bias", {C});
+        }
+    }
+    for (int j = 0; j < L; ++j) {
+        std::string p = "decoders." + std::to_string(j) + ".1.conv2d.";
+        put(p + "weight", {bc << (L - 1 - j), bc << (L - j), ks, ks});
+        put(p + "bias", {bc << (L - 1 - j)});
+    }
+    put("predI.1.weight", {1, bc, 1, 1});
+    put("predI.1.bias", {1});
+    return bde_finalize_weights(m);
+}
+
+int64_t bde_packed_numel(const bde_model* m) { return m ? m->dev_numel : 0; }
+float* bde_packed_ptr(bde_model* m) { return m ? m->dev : nullptr; }
+
+int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, int32_t Hp, int32_t Wp,
+                float* const* images, void* stream) {
+    BDE_REQUIRE(m && events && images, "null argument");
+    for (int t = 0; t < T; ++t) BDE_REQUIRE(events[t] && images[t], "null frame pointer at t=%d", t);
+    return forward_impl(m, events, T, B, Hp, Wp, images, (hipStream_t)stream);
+}
+
+int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream) {
+    BDE_REQUIRE(m && name && dst, "null argument");
+    Workspace& ws = m->ws;
+    BDE_REQUIRE(ws.T > 0, "no forward has run");
+    const long TB = (long)ws.T * ws.B;
+    const float* src = nullptr;
+    long n = 0;
+    std::string nm(name);
+    if (nm == "head") {
+        src = ws.head;
+        n = TB * m->cfg.basechannels * ws.H * ws.W;
+    } else if (nm.rfind("merged", 0) == 0) {
+        int l = atoi(nm.c_str() + 6);
+        BDE_REQUIRE(l >= 0 && l < m->L, "level %d", l);
+        src = ws.merged[l];
+        n = TB * m->cout(l) * (long)(ws.H >> (l + 1)) * (ws.W >> (l + 1));
+    } else if (nm.rfind("dec", 0) == 0) {
+        int j = atoi(nm.c_str() + 3);
+        BDE_REQUIRE(j >= 0 && j < m->L, "decoder %d", j);
+        const int l = m->L - 1 - j;
+        src = ws.dec[j];
+        n = TB * m->cin(l) * (long)(ws.H >> l) * (ws.W >> l);
+    } else {
+        return fail(BDE_ERR_ARG, "unknown intermediate '%s'", name);
+    }
+    BDE_REQUIRE(numel == n, "intermediate '%s' has %ld values, caller asked for %ld", name, n, (long)numel);
+    BDE_HIP(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BDE_OK;
+}
+
+int bde_voxelize(const float* xs, const float* ys, const float* ts, const float* ps, int64_t N, int32_t num_bins,
+                 int32_t H, int32_t W, float* grid, int32_t* oob_count, void* stream) {
+    BDE_REQUIRE(grid && num_bins >= 1 && H >= 1 && W >= 1 && N >= 0, "bad argument");
+    BDE_REQUIRE(N == 0 || (xs && ys && ts && ps), "null event array");
+    return voxel_launch(xs, ys, ts, ps, nullptr, 1, (long)N, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
+}
+
+int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const float* ps, const int64_t* offsets,
+                       int32_t nseg, int64_t max_events_per_seg, int32_t num_bins, int32_t H, int32_t W, float* grids,
+                       int32_t* oob_count, void* stream) {
+    BDE_REQUIRE(grids && offsets && nseg >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
+    BDE_REQUIRE(xs && ys && ts && ps, "null event array");
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
+    return voxel_launch(xs, ys, ts, ps, (const long*)offsets, nseg, (long)max_events_per_seg, num_bins, H, W, grids,
+                        oob_count, (hipStream_t)stream);
+}
+
+// ---- single sub-modules ----------------------------------------------------------------------
+int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
+    BDE_REQUIRE(m && m->finalized && in && out, "bad argument");
+    ConvCall c;
+    c.pl = &m->head; c.in = in; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.act = ACT_RELU;
+    return run_conv(m, c, (hipStream_t)stream);
+}
+
+int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t N, int32_t H, int32_t W,
+                        float* out, void* stream) {
+    BDE_REQUIRE(m && m->finalized && in && out && level >= 0 && level < m->L && (dir == 0 || dir == 1), "bad argument");
+    PackedLayer pl = m->enc[level];   // view of a single direction
+    pl.G = 1;
+    pl.w_off += dir * pl.w_sz;
+    pl.b_off += (long)dir * pl.Cout;
+    ConvCall c;
+    c.pl = &pl; c.in = in; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.stride = 2; c.act = ACT_RELU;
+    return run_conv(m, c, (hipStream_t)stream);
+}
+
+int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t T, int32_t B, int32_t H,
+                          int32_t W, float* h_out, float* c_out, void* stream) {
+    BDE_REQUIRE(m && m->finalized && in && h_out && level >= 0 && level < m->L && (dir == 0 || dir == 1), "bad argument");
+    BDE_REQUIRE(H % 2 == 0 && W % 2 == 0, "H, W must be even");
+    hipStream_t s = (hipStream_t)stream;
+    // run the level on a private workspace sized for this call (full resolution = H << level)
+    BDE_TRY(ensure_workspace(m, T, B, H << level, W << level));
+    BDE_TRY(run_recurrent_level(m, level, in, T, B, H, W, s));
+    const int C = m->cout(level);
+    const long hw = (long)(H / 2) * (W / 2), TB = (long)T * B;
+    // dir 0 sweeps t = 0..T-1, dir 1 sweeps t = T-1..0 (V5.py:123); h_out[t] belongs to input frame t.
+    BDE_HIP(hipMemcpyAsync(h_out, m->ws.hseq[level] + (long)dir * TB * C * hw, sizeof(float) * TB * C * hw,
+                           hipMemcpyDeviceToDevice, s));
+    if (c_out)
+        BDE_HIP(hipMemcpyAsync(c_out, m->ws.cst[level] + (long)dir * B * C * hw, sizeof(float) * B * C * hw,
+                               hipMemcpyDeviceToDevice, s));
+    return BDE_OK;
+}
+
+int bde_op_decoder(bde_model* m, int32_t j, const float* in, const float* skip, int32_t N, int32_t H, int32_t W,
+                   float* out, void* stream) {
+    BDE_REQUIRE(m && m->finalized && in && out && j >= 0 && j < m->L, "bad argument");
+    ConvCall c;
+    c.pl = &m->dec[j]; c.in = in; c.in2 = skip; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.up2 = true; c.act = ACT_RELU6;
+    return run_conv(m, c, (hipStream_t)stream);
+}
+
+int bde_op_pred(bde_model* m, const float* in, const float* head, int32_t N, int32_t H, int32_t W, float* out,
+                void* stream) {
+    BDE_REQUIRE(m && m->finalized && in && out, "bad argument");
+    const long total = (long)N * H * W;
+    long blocks = std::min<long>(cdivl(total, 256), 4096);
+    hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, head,
+                       m->P(m->predw_off), m->P(m->predb_off), out, m->cfg.basechannels, (long)H * W, total,
+                       m->cfg.activation);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* bufs, int32_t B, int32_t H, int32_t W,
+                            int32_t first_block, int32_t nblocks, float* out, void* stream) {
+    BDE_REQUIRE(m && m->finalized && bufs && out && level >= 0 && level < m->L, "bad argument");
+    const AttnLevel& al = m->attn[level];
+    BDE_REQUIRE(al.depth > 0, "level %d has no attention", level);
+    BDE_REQUIRE(H >= 7 && W >= 7, "map %dx%d smaller than the window", H, W);
+    if (nblocks < 0) { first_block = 0; nblocks = al.depth; }
+    BDE_REQUIRE(first_block >= 0 && first_block + nblocks <= al.depth && nblocks >= 1, "block range");
+    const bde_config& c = m->cfg;
+    BDE_REQUIRE(bufs[c.q_idx] != nullptr, "the query frame must be given");
+    hipStream_t s = (hipStream_t)stream;
+    // workspace: treat this map as level `level` of a (H<<(level+1)) x (W<<(level+1)) input, T = frame_num
+    const int D = c.frame_num;
+    BDE_TRY(ensure_workspace(m, D, B, H << (level + 1), W << (level + 1)));
+    const long HW = (long)H * W;
+    const long kvfs = (long)B * al.depth * 2 * al.C * HW;
+    const float* kvslot[BDE_MAX_FRAMES];
+    for (int d = 0; d < D; ++d) {
+        kvslot[d] = nullptr;
+        if (d == c.q_idx || bufs[d] == nullptr) continue;
+        float* dst = m->ws.kvun[level] + (long)d * kvfs;
+        BDE_TRY(run_pw(m, &al.kvall, bufs[d], dst, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+        kvslot[d] = dst;
+    }
+    return run_attention_frame(m, level, bufs[c.q_idx], kvslot, nullptr, out, B, H, W, first_block, nblocks, s);
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

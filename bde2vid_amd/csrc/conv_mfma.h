@@ -1,0 +1,430 @@
+// Direct (im2col-free) convolution on the gfx950 fp32 matrix cores.
+//
+//   D[co][p] = sum_k A[co][k] * B[k][p],   k = (ci, ky, kx),  p = linear output pixel y*Wo+x
+//
+// One kernel template serves every dense contraction of the BDE2VID path:
+//   * ConvLayer / head / encoder convs            (submodules.py:105-114)     KS 5|3, stride 1|2
+//   * ConvLSTM gates, x-part and recurrent h-part (submodules.py:316-332)     KS 3, LSTM epilogue
+//   * UpsampleConvLayer: bilinear x2 done while staging the LDS tile (submodules.py:137-147)
+//   * every Linear of the window attention / MLP as a 1x1 conv over [C][H*W] planes, with the
+//     LayerNorm folded into the weights and finished in the epilogue (DTransformer.py:183-190,279-283)
+//
+// Mapping onto v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD):
+//   A operand = packed weights, one coalesced 256-B global load per (32 co x 2 ci) fragment,
+//               pre-packed on the host in exactly the lane order the instruction wants;
+//   B operand = input halo tile staged once per channel chunk into LDS ([ci][row][col], planar,
+//               pixels contiguous -> conflict-free ds_read_b32 for stride 1), each lane reading
+//               its own pixel at a wave-uniform (ci,ky,kx) offset: no im2col buffer anywhere;
+//   D         = 32 co x 32 pixels per tile, pixel on the lane -> NCHW stores in 128-B segments.
+// Activations stay NCHW (the reference layout), so the boundary needs no layout conversion.
+//
+// Two wave arrangements (4 waves / 256 threads per workgroup):
+//   SPLITK=false : waves tile the pixel axis  -> block = (MT*32 co) x (4*NT*32 px), no reduction;
+//                  used for the T-batched, non-recurrent launches (thousands of blocks).
+//   SPLITK=true  : waves split the channel chunks of one (MT*32 co) x (NT*32 px) tile and reduce
+//                  through LDS; 4x more, 4x smaller blocks for the sequential per-step launches
+//                  (ConvLSTM step, attention GEMMs) where one frame must fill 256 CUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.h"
+
+namespace bde {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_GELU = 3 };
+enum { EPI_GENERIC = 0, EPI_LSTM = 1 };
+
+struct ConvArgs {
+    // ---- tensors; z = g * N + n selects (group g, frame n) -----------------------------
+    const float* in;     // [G?][N][Cin][Hs][Ws]      (Hs,Ws = source dims; = Hin,Win unless UP2)
+    const float* in2;    // optional, summed with `in` while staging (skip_sum, V5.py:289-293)
+    const float* wpk;    // packed weights [co_tile][chunk][tap][CK/2][64]
+    const float* bias;   // [Cout] (plain) -- already Wb+b when the LayerNorm is folded
+    const float* lnsum;  // [Cout] row sums of the LN-folded weights, nullptr = no LayerNorm
+    const float* res1;   // optional residuals added after the activation, shape of `out`
+    const float* res2;
+    float* out;          // [G?][N][Cout][Ho][Wo]
+    long in_gs, in2_gs, w_gs, bias_gs, res1_gs, res2_gs, out_gs;   // group strides (elements)
+    long in_ns, in2_ns, res1_ns, res2_ns, out_ns;                   // frame strides (elements)
+    int N;               // frames per group (grid.z = G*N)
+    int Cin, Hin, Win;   // logical conv input (after the optional x2 upsample)
+    int Hs, Ws;          // stored input dims
+    int Cout, Ho, Wo;
+    int nchunks;         // channel chunks in the packed weights (multiple of 4 when SPLITK)
+    int act;
+    // dilated-window coverage mask (DTransformer.py:79-82): pixels the fold never writes get
+    // res1+res2 only.  mask_w = map width used to recover (y,x) from p; 0 = off.
+    int mask_w, mask_pt, mask_pl;
+    // ---- EPI_LSTM (group = direction) ---------------------------------------------------
+    const float* gx;     // [G][N][4*Ch][HW]  x-part of the gates incl. bias
+    float* cstate;       // [G][N][Ch][HW]    cell state, updated in place
+    long gx_gs, gx_ns, c_gs, c_ns;
+    int first;           // 1: h_prev == 0 -> skip the contraction entirely
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// Row of accumulator register r inside a 32x32 tile (cdna_hip_programming.md §3).
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int KS, int STRIDE, int MT, int NT, int CK, bool UP2, bool SPLITK, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int TAPS = KS * KS;
+    constexpr int PAIRS = CK / 2;
+    constexpr int WN = SPLITK ? 1 : 4;        // waves along the pixel axis
+    constexpr int BN = WN * NT * 32;          // pixels per block
+    constexpr int STAGE_C = SPLITK ? 4 * CK : CK;   // channels staged per barrier pair
+    extern __shared__ __align__(16) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int z = blockIdx.z;
+    const int g = z / a.N, n = z - g * a.N;
+    const int HW = a.Ho * a.Wo;
+    const int p0 = blockIdx.x * BN;
+    const int p_last = min(p0 + BN, HW) - 1;
+    const int y_first = p0 / a.Wo, y_last = p_last / a.Wo;
+    const bool one_row = (y_first == y_last);
+    const int x_first = p0 - y_first * a.Wo;
+    const int iy0 = y_first * STRIDE - PAD;
+    const int ix0 = one_row ? x_first * STRIDE - PAD : -PAD;
+    const int R = (y_last - y_first) * STRIDE + KS;
+    const int IW = one_row ? (p_last - p0) * STRIDE + KS : a.Win + 2 * PAD;
+    const int PS = R * IW;                    // LDS plane stride (one input channel)
+
+    // per-lane LDS offset of each of this wave's pixel tiles (tap (0,0), even channel of a pair)
+    int boff[NT];
+    int pix[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int p = p0 + ((SPLITK ? 0 : wave * NT) + t) * 32 + (lane & 31);
+        pix[t] = p;
+        int pc = min(p, p_last);
+        int y = pc / a.Wo, x = pc - y * a.Wo;
+        boff[t] = (y - y_first) * STRIDE * IW + (x * STRIDE - PAD - ix0) + (lane >> 5) * PS;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    float s1[NT], s2[NT];   // per-pixel sum / sum of squares of the B operand (LayerNorm fold)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.f;
+    const bool want_ln = (a.lnsum != nullptr);
+
+    const bool skip_mac = (EPI == EPI_LSTM) && a.first;
+    if (!skip_mac) {
+        const float* inb = a.in + g * a.in_gs + n * a.in_ns;
+        const float* in2b = a.in2 ? a.in2 + g * a.in2_gs + n * a.in2_ns : nullptr;
+        const float* wg = a.wpk + g * a.w_gs;
+        const long HsWs = (long)a.Hs * a.Ws;
+        const int tile_elems = R * IW;
+        const float inv_iw = 1.0f / (float)IW;
+        const int nstages = SPLITK ? a.nchunks / 4 : a.nchunks;
+        for (int st = 0; st < nstages; ++st) {
+            const int c0 = st * STAGE_C;
+            __syncthreads();   // previous stage fully consumed
+            // ---- stage STAGE_C input channels of the halo tile into LDS ------------------
+            for (int e = tid; e < tile_elems; e += 256) {
+                int r = (int)(((float)e + 0.5f) * inv_iw);
+                int col = e - r * IW;
+                int iy = iy0 + r, ix = ix0 + col;
+                bool ok = (iy >= 0) && (iy < a.Hin) && (ix >= 0) && (ix < a.Win);
+                float* dst = lds + e;
+                if constexpr (!UP2) {
+                    const long off = (long)iy * a.Ws + ix;
+#pragma unroll 8
+                    for (int ci = 0; ci < STAGE_C; ++ci) {
+                        float v = 0.f;
+                        if (ok && (c0 + ci) < a.Cin) {
+                            v = inb[(long)(c0 + ci) * HsWs + off];
+                            if (in2b) v += in2b[(long)(c0 + ci) * HsWs + off];
+                        }
+                        dst[ci * PS] = v;
+                    }
+                } else {
+                    // bilinear x2, align_corners=False: src = (dst+0.5)/2-0.5 clamped at 0;
+                    // even dst -> 0.25*in[i-1]+0.75*in[i], odd -> 0.75*in[i]+0.25*in[i+1], edges clamp
+                    int ya = max((iy - 1) >> 1, 0), yb = min((iy + 1) >> 1, a.Hs - 1);
+                    int xa = max((ix - 1) >> 1, 0), xb = min((ix + 1) >> 1, a.Ws - 1);
+                    if (iy == 0) ya = yb = 0;
+                    if (ix == 0) xa = xb = 0;
+                    float wyb = (iy & 1) ? 0.25f : 0.75f, wxb = (ix & 1) ? 0.25f : 0.75f;
+                    if (iy == 0 || ya == yb) wyb = 1.f;   // clamped edge: both taps coincide
+                    if (ix == 0 || xa == xb) wxb = 1.f;
+                    // torch: lambda1 (weight of the upper/right tap) = frac(src); for odd dst 0.25, even 0.75
+                    float wya = 1.f - wyb, wxa = 1.f - wxb;
+                    const long o00 = (long)ya * a.Ws + xa, o01 = (long)ya * a.Ws + xb;
+                    const long o10 = (long)yb * a.Ws + xa, o11 = (long)yb * a.Ws + xb;
+#pragma unroll 4
+                    for (int ci = 0; ci < STAGE_C; ++ci) {
+                        float v = 0.f;
+                        if (ok && (c0 + ci) < a.Cin) {
+                            const float* s = inb + (long)(c0 + ci) * HsWs;
+                            float v00 = s[o00], v01 = s[o01], v10 = s[o10], v11 = s[o11];
+                            if (in2b) {
+                                const float* s2p = in2b + (long)(c0 + ci) * HsWs;
+                                v00 += s2p[o00]; v01 += s2p[o01]; v10 += s2p[o10]; v11 += s2p[o11];
+                            }
+                            v = wya * (wxa * v00 + wxb * v01) + wyb * (wxa * v10 + wxb * v11);
+                        }
+                        dst[ci * PS] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- contraction over this stage's channels ---------------------------------
+            const int chunk = SPLITK ? st * 4 + wave : st;
+            const float* ldsw = lds + (SPLITK ? wave * CK * PS : 0);
+            const float* wch[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                wch[m] = wg + (((long)(blockIdx.y * MT + m) * a.nchunks + chunk) * TAPS * PAIRS) * 64 + lane;
+            if (want_ln) {   // only used with KS == 1
+#pragma unroll
+                for (int pr = 0; pr < PAIRS; ++pr)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        float b = ldsw[boff[t] + pr * 2 * PS];
+                        s1[t] += b;
+                        s2[t] += b * b;
+                    }
+            }
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int tap = ky * KS + kx;
+#pragma unroll
+                    for (int pr = 0; pr < PAIRS; ++pr) {
+                        float av[MT], bv[NT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) av[m] = wch[m][(tap * PAIRS + pr) * 64];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) bv[t] = ldsw[boff[t] + pr * 2 * PS + ky * IW + kx];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // ---- split-K reduction through LDS, one register quarter per phase: in phase q every wave
+    //      publishes registers [4q,4q+4) of all its tiles and wave q sums the four copies, so wave
+    //      w finishes rows acc_row(4w..4w+3) of every tile (scratch: MT*NT*4 KiB).
+    constexpr int RPW = SPLITK ? 4 : 16;     // accumulator registers this wave finalises
+    const int r0 = SPLITK ? wave * 4 : 0;
+    float fin[MT][NT][RPW];
+    if constexpr (SPLITK) {
+        if (skip_mac) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) fin[m][t][rr] = 0.f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            lds[((((wave * MT + m) * NT + t) * 4) + rr) * 64 + lane] = acc[m][t][4 * q + rr];
+                if (want_ln && q == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        lds[MT * NT * 1024 + (wave * NT + t) * 128 + lane] = s1[t];
+                        lds[MT * NT * 1024 + (wave * NT + t) * 128 + 64 + lane] = s2[t];
+                    }
+                }
+                __syncthreads();
+                if (wave == q) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                float v = 0.f;
+#pragma unroll
+                                for (int w = 0; w < 4; ++w)
+                                    v += lds[((((w * MT + m) * NT + t) * 4) + rr) * 64 + lane];
+                                fin[m][t][rr] = v;
+                            }
+                }
+                if (want_ln && q == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        float u = 0.f, v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            u += lds[MT * NT * 1024 + (w * NT + t) * 128 + lane];
+                            v += lds[MT * NT * 1024 + (w * NT + t) * 128 + 64 + lane];
+                        }
+                        s1[t] = u;
+                        s2[t] = v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) fin[m][t][rr] = acc[m][t][rr];
+    }
+
+    // ---- LayerNorm statistics of each lane's pixel (both k-parities summed) -------------------
+    float mu[NT], rstd[NT];
+    if (want_ln) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float u = s1[t] + __shfl_xor(s1[t], 32);
+            float v = s2[t] + __shfl_xor(s2[t], 32);
+            float mean = u / (float)a.Cin;
+            float var = fmaxf(v / (float)a.Cin - mean * mean, 0.f);
+            mu[t] = mean;
+            rstd[t] = 1.0f / sqrtf(var + 1e-5f);
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    if constexpr (EPI == EPI_GENERIC) {
+        float* outb = a.out + g * a.out_gs + n * a.out_ns;
+        const float* r1 = a.res1 ? a.res1 + g * a.res1_gs + n * a.res1_ns : nullptr;
+        const float* r2 = a.res2 ? a.res2 + g * a.res2_gs + n * a.res2_ns : nullptr;
+        const float* biasg = a.bias + g * a.bias_gs;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = pix[t];
+            if (p >= HW) continue;
+            bool covered = true;
+            if (a.mask_w > 0) {
+                int y = p / a.mask_w, x = p - y * a.mask_w;
+                int rr = y + a.mask_pt, cc = x + a.mask_pl;
+                covered = !((rr < 7 && (rr & 1)) || (cc < 7 && (cc & 1)));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int cob = (blockIdx.y * MT + m) * 32;
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int co = cob + acc_row(r0 + rr, lane);
+                    if (co >= a.Cout) continue;
+                    float v = fin[m][t][rr];
+                    if (want_ln) v = rstd[t] * (v - mu[t] * a.lnsum[co]);
+                    v = act_apply(v + biasg[co], a.act);
+                    if (!covered) v = 0.f;
+                    const long o = (long)co * HW + p;
+                    if (r1) v += r1[o];
+                    if (r2) v += r2[o];
+                    outb[o] = v;
+                }
+            }
+        }
+    } else {
+        // ConvLSTM pointwise (submodules.py:320-332): tiles m = gate i,f,o,g of the same 32 hidden
+        // channels; acc holds W_h * h_prev, gx holds W_x * x + bias.
+        static_assert(EPI != EPI_LSTM || MT == 4, "LSTM epilogue needs the four gate tiles");
+        const int Ch = a.Cout / 4;
+        float* hout = a.out + g * a.out_gs + n * a.out_ns;
+        float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
+        const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = pix[t];
+            if (p >= HW) continue;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int hc = blockIdx.y * 32 + acc_row(r0 + rr, lane);
+                if (hc >= Ch) continue;
+                const long o = (long)hc * HW + p;
+                float gi = fin[0][t][rr] + gxb[o];
+                float gf = fin[1][t][rr] + gxb[(long)Ch * HW + o];
+                float go = fin[2][t][rr] + gxb[(long)2 * Ch * HW + o];
+                float gg = fin[3][t][rr] + gxb[(long)3 * Ch * HW + o];
+                float cprev = a.first ? 0.f : cst[o];
+                float c = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+                float h = sigmoidf_(go) * tanhf(c);
+                cst[o] = c;
+                hout[o] = h;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: geometry, LDS sizing, launch
+// ------------------------------------------------------------------------------------------
+struct ConvGeom {
+    int KS, STRIDE, MT, NT, CK;
+    bool up2, splitk;
+    int epi;
+};
+
+// Exact LDS requirement: max over blocks of (channels staged) * R * IW floats (+ split-K scratch).
+static inline size_t conv_lds_bytes(const ConvGeom& gm, int Win, int Ho, int Wo, bool ln) {
+    const int PAD = gm.KS / 2;
+    const int BN = (gm.splitk ? 1 : 4) * gm.NT * 32;
+    const int HW = Ho * Wo;
+    long best = 0;
+    for (int p0 = 0; p0 < HW; p0 += BN) {
+        int pl = (p0 + BN < HW ? p0 + BN : HW) - 1;
+        int yf = p0 / Wo, yl = pl / Wo;
+        int R = (yl - yf) * gm.STRIDE + gm.KS;
+        int IW = (yf == yl) ? (pl - p0) * gm.STRIDE + gm.KS : Win + 2 * PAD;
+        long e = (long)R * IW;
+        if (e > best) best = e;
+    }
+    long stage = (long)(gm.splitk ? 4 * gm.CK : gm.CK) * best;
+    long red = gm.splitk ? (long)gm.MT * gm.NT * 1024 + (ln ? 4 * gm.NT * 128 : 0) : 0;
+    long fl = stage > red ? stage : red;
+    return (size_t)fl * sizeof(float);
+}
+
+template <int KS, int STRIDE, int MT, int NT, int CK, bool UP2, bool SPLITK, int EPI>
+static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
+    ConvGeom gm{KS, STRIDE, MT, NT, CK, UP2, SPLITK, EPI};
+    const size_t lds = conv_lds_bytes(gm, a.Win, a.Ho, a.Wo, a.lnsum != nullptr);
+    if (lds > 160 * 1024)
+        return fail(BDE_ERR_UNSUPPORTED, "conv tile needs %zu B of LDS (> 160 KiB): Win=%d KS=%d CK=%d", lds,
+                    a.Win, KS, CK);
+    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, CK, UP2, SPLITK, EPI>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    constexpr int BN = (SPLITK ? 1 : 4) * NT * 32;
+    const int co_rows = (EPI == EPI_LSTM) ? a.Cout / 4 : a.Cout;          // LSTM: 32 hidden ch per block
+    const int co_per_block = (EPI == EPI_LSTM) ? 32 : MT * 32;
+    dim3 grid(cdiv(a.Ho * a.Wo, BN), cdiv(co_rows, co_per_block), G * a.N);
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+}  // namespace bde

@@ -1,0 +1,80 @@
+// Event -> voxel-grid binning as an atomic scatter.
+//
+// Restates events_to_voxel_torch (events_contrast_maximization/utils/event_utils.py:466-509) and the
+// nearest-pixel branch of events_to_image_torch (:360,371-375).  The reference makes B full passes
+// over the N events (one index_put_(accumulate) per bin); the temporal-bilinear weight
+// max(0, 1-|t_norm-b|) is non-zero for at most two bins, so one pass with two float atomics per
+// event produces the same grid.  Per-event weights are computed with the reference's exact fp32
+// expression, so they are bit-identical; only the summation ORDER inside a pixel differs
+// (float atomics), which is why parity for this kernel is 1e-5*max(1,count) instead of bit-exact.
+//
+// HBM/atomic-bound: 16 B read per event + 2 no-return global_atomic_add_f32; the grid is zero-filled
+// in the same call.  MI355X executes float atomics at the memory side (~1.3 TB/s of added bytes,
+// MI355X_MICROARCH.md "Global float atomics"), so no LDS privatisation is attempted: a 5x180x240
+// grid (864 KB) would not fit one CU's LDS anyway.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.h"
+
+namespace bde {
+
+__global__ __launch_bounds__(256) void voxel_scatter_kernel(const float* __restrict__ xs,
+                                                            const float* __restrict__ ys,
+                                                            const float* __restrict__ ts,
+                                                            const float* __restrict__ ps,
+                                                            const long* __restrict__ offsets, long n_single,
+                                                            int nb, int H, int W, float* __restrict__ grids,
+                                                            int* __restrict__ oob) {
+    const int seg = blockIdx.y;
+    const long beg = offsets ? offsets[seg] : 0;
+    const long end = offsets ? offsets[seg + 1] : n_single;
+    const long n = end - beg;
+    if (n <= 0) return;
+    float* grid = grids + (long)seg * nb * H * W;
+    const float t0 = ts[beg];
+    const float dt = ts[end - 1] - t0;                 // event_utils.py:489
+    const float bm1 = (float)(nb - 1);
+    const long HW = (long)H * W;
+    for (long i = beg + blockIdx.x * (long)blockDim.x + threadIdx.x; i < end; i += (long)gridDim.x * blockDim.x) {
+        const float tn = (ts[i] - t0) / dt * bm1;      // :490  (division, then multiply, fp32)
+        long xi = (long)xs[i], yi = (long)ys[i];       // :371-374  Tensor.long() truncates toward zero
+        if (xi < 0) xi += W;                           // index_put_ wraps negative indices
+        if (yi < 0) yi += H;
+        if (xi < 0 || xi >= W || yi < 0 || yi >= H) {  // the reference raises IndexError here
+            if (oob) atomicAdd(oob, 1);
+            continue;
+        }
+        const float p = ps[i];
+        float* cell = grid + yi * W + xi;
+        if (!(tn == tn)) {                             // dt == 0 -> NaN weights in every bin (:494-495)
+            for (int b = 0; b < nb; ++b) atomicAdd(cell + b * HW, p * tn);
+            continue;
+        }
+        const int b0 = (int)floorf(tn);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b0 + k;
+            if (b < 0 || b >= nb) continue;
+            const float w = fmaxf(0.f, 1.0f - fabsf(tn - (float)b));   // :494
+            const float v = p * w;                                      // :495
+            if (v != 0.f) atomicAdd(cell + b * HW, v);
+        }
+    }
+}
+
+static inline int voxel_launch(const float* xs, const float* ys, const float* ts, const float* ps,
+                               const long* offsets, int nseg, long n_per_seg_max, int nb, int H, int W,
+                               float* grids, int* oob, hipStream_t stream) {
+    BDE_HIP(hipMemsetAsync(grids, 0, sizeof(float) * (size_t)nseg * nb * H * W, stream));
+    if (oob) BDE_HIP(hipMemsetAsync(oob, 0, sizeof(int), stream));
+    if (n_per_seg_max <= 0) return BDE_OK;
+    long blocks = cdivl(n_per_seg_max, 256);
+    if (blocks > 2048) blocks = 2048;                  // grid-stride the rest
+    dim3 grid((unsigned)blocks, (unsigned)nseg);
+    hipLaunchKernelGGL(voxel_scatter_kernel, grid, dim3(256), 0, stream, xs, ys, ts, ps, offsets, n_per_seg_max,
+                       nb, H, W, grids, oob);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+}  // namespace bde

@@ -1,0 +1,128 @@
+/*
+ * libbde2vid -- C ABI of the MI355X-native BDE2VID inference path.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  Every pointer is a raw pointer (device pointers
+ * come from tensor.data_ptr()); no torch types, no C++ types, no exceptions cross it.  Functions
+ * return 0 on success and a negative status otherwise; bde_last_error() then describes the failure.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   bde_create / bde_load_weight / bde_finalize_weights
+ *       <- MODELS.build(cfg.model) + model.load_state_dict(sd)   eval_models_seq.py:52-60,86
+ *          (module tree of model/BDE2VID/bde2vid.py:14-20 and
+ *           model/BDE2VID/bde2vid_cross_scale_propogation_V5.py:19-98)
+ *   bde_forward
+ *       <- BDE2VID.forward(inputs, mode='tensor')               model/BDE2VID/bde2vid.py:30-50
+ *          == BDE2VIDCrossscalePropogationV5.forward            ..._V5.py:100-241
+ *   bde_voxelize / bde_voxelize_batch
+ *       <- events_to_voxel_torch                                events_contrast_maximization/utils/event_utils.py:466-509
+ *          (+ events_to_image_torch nearest branch, :330-376), called from data_loader/h5_dataset.py:357
+ *   bde_op_*  (one reference sub-module each; used by the per-block parity tests)
+ *       <- ConvLayer.forward            model/BDE2VID/submodules.py:105-114
+ *          RecurrentConv.forward        model/BDE2VID/submodules.py:191-195 (+ConvLSTM.forward :293-334)
+ *          UpsampleConvLayer.forward    model/BDE2VID/submodules.py:137-147
+ *          DFrameAttention.forward      model/BDE2VID/DTransformer.py:376-389
+ *          predI + activation           ..._V5.py:195-197
+ */
+#ifndef BDE2VID_H
+#define BDE2VID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDE_MAX_LEVELS 8
+#define BDE_MAX_FRAMES 8
+
+typedef struct bde_model bde_model;
+
+/* Generator hyper-parameters (constructor arguments of the reference generator, V5.py:19-23).
+ * Fixed by this build: norm=None, convlstm, useRC, skip 'sum', 7x7 windows, nwindow_size=None. */
+typedef struct bde_config {
+    int32_t num_bins;                      /* input channels (5) */
+    int32_t basechannels;                  /* 32 */
+    int32_t num_encoders;                  /* 3 */
+    int32_t ks;                            /* 5 (or 3) */
+    int32_t num_heads;                     /* 16 */
+    int32_t frame_num;                     /* len(buffer_index) */
+    int32_t q_idx;                         /* slot of the query frame; buffer_index[q_idx] must be 0 */
+    int32_t activation;                    /* 0 = Identity, 1 = Sigmoid */
+    int32_t depths[BDE_MAX_LEVELS];        /* attention blocks per level (0 = none) */
+    int32_t buffer_index[BDE_MAX_FRAMES];  /* temporal offsets of the attention buffer */
+} bde_config;
+
+/* status codes */
+#define BDE_OK 0
+#define BDE_ERR_ARG (-1)
+#define BDE_ERR_STATE (-2)
+#define BDE_ERR_HIP (-3)
+#define BDE_ERR_UNSUPPORTED (-4)
+
+const char* bde_last_error(void);
+int bde_abi_version(void);
+
+/* ---- model life cycle --------------------------------------------------------------------- */
+int bde_create(const bde_config* cfg, bde_model** out);
+void bde_destroy(bde_model* m);
+/* `data` is a HOST pointer to a contiguous fp32 tensor; `key` is the reference state_dict key
+ * (SURVEY.md Appendix B).  Unknown keys that the forward path never reads (fusion_layers.*,
+ * relative_position_index) are accepted and ignored. */
+int bde_load_weight(bde_model* m, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+/* Checks that every tensor of the forward path is present with the right shape, folds the
+ * LayerNorms / query scale into the projection weights, packs everything into MFMA fragment
+ * order and uploads it to the current HIP device. */
+int bde_finalize_weights(bde_model* m);
+/* Number of fp32 values of the packed device image, and raw access for the RCCL broadcast
+ * (bde2vid_amd/dist.py): rank 0 finalizes, the others allocate with bde_alloc_packed and receive. */
+int64_t bde_packed_numel(const bde_model* m);
+float* bde_packed_ptr(bde_model* m);
+int bde_alloc_packed(bde_model* m);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* events[t]: device fp32 [B][num_bins][Hp][Wp] (NCHW);  images[t]: device fp32 [B][1][Hp][Wp].
+ * Hp, Wp multiples of 2^num_encoders, feature maps at attention levels >= 7x7.
+ * Recurrent state always starts from zero (bde2vid.py:31).  Launches on `stream`, returns
+ * without synchronising. */
+int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, int32_t Hp, int32_t Wp,
+                float* const* images, void* stream);
+/* Copy a named intermediate of the last bde_forward into `dst` (device): "head", "merged<l>"
+ * (level output after attention), "dec<j>".  Layout [T][B][C][H][W]. */
+int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream);
+
+/* Event -> voxel grid.  xs, ys, ts, ps: device fp32 [N] (ts sorted ascending);
+ * grid: device fp32 [num_bins][H][W], overwritten.  oob_count (device int32, may be NULL) receives
+ * the number of events whose pixel index fell outside the sensor (the reference raises there). */
+int bde_voxelize(const float* xs, const float* ys, const float* ts, const float* ps, int64_t N,
+                 int32_t num_bins, int32_t H, int32_t W, float* grid, int32_t* oob_count, void* stream);
+/* nseg packets in one launch: packet s owns events [offsets[s], offsets[s+1]) (device int64
+ * [nseg+1]) and writes grid[s]. */
+int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const float* ps,
+                       const int64_t* offsets, int32_t nseg, int64_t max_events_per_seg, int32_t num_bins,
+                       int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream);
+
+/* ---- single reference sub-modules (parity tests) ------------------------------------------- */
+int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream);
+/* RecurrentConv of level `level`, direction `dir` (0 forward_encoder, 1 backward_encoder) applied
+ * to T consecutive inputs in[t] = [B][Cin][H][W] starting from zero state; h_out [T][B][C][H/2][W/2],
+ * c_out [B][C][H/2][W/2] (final cell state).  dir 0 sweeps t = 0..T-1, dir 1 sweeps t = T-1..0
+ * (V5.py:123); h_out[t] always belongs to input frame t. */
+int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t T, int32_t B,
+                          int32_t H, int32_t W, float* h_out, float* c_out, void* stream);
+int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t N, int32_t H,
+                        int32_t W, float* out, void* stream);
+/* decoder j: out = ReLU6(conv(bilinear_x2(in + skip)))); skip may be NULL */
+int bde_op_decoder(bde_model* m, int32_t j, const float* in, const float* skip, int32_t N, int32_t H, int32_t W,
+                   float* out, void* stream);
+int bde_op_pred(bde_model* m, const float* in, const float* head, int32_t N, int32_t H, int32_t W, float* out,
+                void* stream);
+/* DFrameAttention of `level` on a buffer of frame_num frames [B][C][H][W]; bufs[d] == NULL is a
+ * zero frame.  nblocks < 0 runs all blocks, otherwise only block `first_block` .. +nblocks. */
+int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* bufs, int32_t B, int32_t H,
+                            int32_t W, int32_t first_block, int32_t nblocks, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDE2VID_H */
