@@ -38,6 +38,8 @@ SIGNATURES = {
     'bde_alloc_packed': (_I, [_P]),
     'bde_forward': (_I, [_P, _PP, _I, _I, _I, _I, _PP, _P]),
     'bde_get_intermediate': (_I, [_P, C.c_char_p, _P, _L, _P]),
+    'bde_profile_reset': (_I, [_P, _I]),
+    'bde_profile_get': (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_L)]),
     'bde_voxelize': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'bde_voxelize_batch': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
     'bde_op_head': (_I, [_P, _P, _I, _I, _I, _P, _P]),
@@ -59,6 +61,10 @@ def lib():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). '
                 'bde2vid_amd has no CPU/PyTorch fallback.')
+        # PyTorch-ROCm ships its own libamdhip64; it must be the one HIP runtime of the process
+        # (device pointers and streams cross between torch and this library), so make sure it is
+        # mapped before libbde2vid.so resolves its libamdhip64.so.N dependency.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the ABI and the binding drift apart

@@ -11,6 +11,7 @@
 // online softmax.  K/V of the window are staged in LDS ([n][hd+4], broadcast float4 reads).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "common.h"
 
 namespace bde {
@@ -37,7 +38,8 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const AttnArgs a) {
     constexpr int HS = HD + 4;                       // padded LDS row (keeps float4 alignment)
     extern __shared__ __align__(16) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int head = blockIdx.y * 4 + wave;
+    const int wpb = blockDim.x >> 6;                 // waves (= heads) per block, sized by LDS
+    const int head = blockIdx.y * wpb + wave;
     const int win = blockIdx.x, b = blockIdx.z;
     if (head >= a.heads) return;                     // whole wave exits; no block-level barrier below
     const int N = a.D * ATT_TOK;
@@ -132,9 +134,12 @@ static inline int attn_launch(const AttnArgs& a, int B, hipStream_t stream) {
     const int hd = a.C / a.heads;
     const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
     const int N = a.D * ATT_TOK;
-    dim3 grid(nW, cdiv(a.heads, 4), B), block(256);
-    const size_t lds = (size_t)4 * 2 * N * (hd + 4) * sizeof(float);
-    if (lds > 160 * 1024) return fail(BDE_ERR_UNSUPPORTED, "attention: head_dim %d x %d keys exceeds LDS", hd, N);
+    const size_t per_wave = (size_t)2 * N * (hd + 4) * sizeof(float);
+    int wpb = (int)std::min<size_t>(4, (160 * 1024) / per_wave);
+    if (wpb < 1) return fail(BDE_ERR_UNSUPPORTED, "attention: head_dim %d x %d keys exceeds LDS", hd, N);
+    wpb = std::min(wpb, a.heads);
+    dim3 grid(nW, cdiv(a.heads, wpb), B), block(64 * wpb);
+    const size_t lds = per_wave * wpb;
 #define BDE_ATT_CASE(HDV)                                                                             \
     case HDV: {                                                                                       \
         auto kern = attn_core_kernel<HDV>;                                                            \

@@ -285,6 +285,11 @@ struct bde_model {
     long predw_off = -1, predb_off = -1;
     Workspace ws;
     int device = 0;
+    // optional HIP-event timing of tagged launches / stages (bde_profile_*)
+    bool prof_on = false;
+    struct ProfSpan { std::string name; hipEvent_t a, b; };
+    std::vector<ProfSpan> prof;
+    std::vector<hipEvent_t> prof_pool;
 
     int cin(int l) const { return cfg.basechannels << l; }
     int cout(int l) const { return cfg.basechannels << (l + 1); }
@@ -292,6 +297,27 @@ struct bde_model {
 };
 
 namespace bde {
+
+// ---- event-pair profiling ---------------------------------------------------------------------
+static hipEvent_t prof_event(bde_model* m) {
+    hipEvent_t e;
+    if (!m->prof_pool.empty()) { e = m->prof_pool.back(); m->prof_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct ProfScope {
+    bde_model* m; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; const char* name;
+    ProfScope(bde_model* m_, const char* n, hipStream_t s_) : m(m_), s(s_), name(n) {
+        if (!m->prof_on) return;
+        a = prof_event(m); b = prof_event(m);
+        if (a) (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!m->prof_on || !a || !b) return;
+        (void)hipEventRecord(b, s);
+        m->prof.push_back({name, a, b});
+    }
+};
 
 static const std::string GP = "generator.";
 
@@ -643,7 +669,7 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     e.act = ACT_RELU;
     e.in_gs = 0;
     e.out_gs = TB * C * hw;
-    BDE_TRY(run_conv(m, e, s));
+    { ProfScope ps(m, "enc_conv", s); BDE_TRY(run_conv(m, e, s)); }
     // x-part of the gates for every t (non-recurrent): gx = conv3x3(x; W[:, :C]) + bias
     ConvCall gxc;
     gxc.pl = &m->gx[l];
@@ -654,7 +680,7 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     gxc.Ws = w;
     gxc.in_gs = TB * C * hw;
     gxc.out_gs = TB * 4 * C * hw;
-    BDE_TRY(run_conv(m, gxc, s));
+    { ProfScope ps(m, "gates_x", s); BDE_TRY(run_conv(m, gxc, s)); }
     // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
     const PackedLayer& pl = m->lstm[l];
     float* hs = ws.hseq[l];
@@ -691,7 +717,11 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         a.Ho = h;
         a.Wo = w;
         a.nchunks = pl.nchunks;
-        BDE_TRY(launch_variant(pl.v, a, 2, s));
+        {
+            static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
+            ProfScope ps(m, names[l], s);
+            BDE_TRY(launch_variant(pl.v, a, 2, s));
+        }
     }
     return BDE_OK;
 }
@@ -802,6 +832,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
                         hipStream_t s) {
     BDE_TRY(check_dims(m, T, B, H, W));
     BDE_TRY(ensure_workspace(m, T, B, H, W));
+    ProfScope whole(m, "forward", s);
     const bde_config& c = m->cfg;
     Workspace& ws = m->ws;
     const int L = c.num_encoders;
@@ -818,7 +849,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     hc.Hs = H;
     hc.Ws = W;
     hc.act = ACT_RELU;
-    BDE_TRY(run_conv(m, hc, s));
+    { ProfScope ps(m, "head", s); BDE_TRY(run_conv(m, hc, s)); }
     // B. levels (V5.py:119-172)
     const float* target = ws.head;
     for (int l = 0; l < L; ++l) {
@@ -826,7 +857,11 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
         BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s));
         const long n = TB * C * h * w;
         BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s));   // V5.py:137-147
-        if (c.depths[l] > 0) BDE_TRY(run_attention_level(m, l, T, B, h, w, s));
+        if (c.depths[l] > 0) {
+            static const char* names[BDE_MAX_LEVELS] = {"attn0", "attn1", "attn2", "attn3", "attn4", "attn5", "attn6", "attn7"};
+            ProfScope ps(m, names[l], s);
+            BDE_TRY(run_attention_level(m, l, T, B, h, w, s));
+        }
         target = ws.merged[l];
     }
     // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x)
@@ -843,7 +878,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
         d.Ws = W >> (l + 1);
         d.up2 = true;
         d.act = ACT_RELU6;
-        BDE_TRY(run_conv(m, d, s));
+        { ProfScope ps(m, "decoder", s); BDE_TRY(run_conv(m, d, s)); }
         x = ws.dec[j];
     }
     {
@@ -905,6 +940,8 @@ void bde_destroy(bde_model* m) {
     if (!m) return;
     m->ws.release();
     if (m->dev) (void)hipFree(m->dev);
+    for (auto& sp : m->prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : m->prof_pool) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -985,6 +1022,31 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
     BDE_REQUIRE(m && events && images, "null argument");
     for (int t = 0; t < T; ++t) BDE_REQUIRE(events[t] && images[t], "null frame pointer at t=%d", t);
     return forward_impl(m, events, T, B, Hp, Wp, images, (hipStream_t)stream);
+}
+
+int bde_profile_reset(bde_model* m, int32_t enable) {
+    BDE_REQUIRE(m != nullptr, "null model");
+    for (auto& sp : m->prof) { m->prof_pool.push_back(sp.a); m->prof_pool.push_back(sp.b); }
+    m->prof.clear();
+    m->prof_on = enable != 0;
+    return BDE_OK;
+}
+
+int bde_profile_get(bde_model* m, const char* name, double* total_ms, int64_t* count) {
+    BDE_REQUIRE(m && name && total_ms && count, "null argument");
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& sp : m->prof) {
+        if (sp.name != name) continue;
+        BDE_HIP(hipEventSynchronize(sp.b));
+        float ms = 0.f;
+        BDE_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *count = n;
+    return BDE_OK;
 }
 
 int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream) {

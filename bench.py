@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reconstructed frames/s of BDE2VID.forward on MI355X.
+
+A step = one `model.forward` over one synthetic sequence (BASELINE.json configs[1]:
+single MI355X, 5x240x180 voxels padded to 5x184x240, seq_len 16, fp32, batch 1, config "A").
+Inputs are voxel grids produced by the HIP scatter from synthetic events and are resident in HBM
+before the timed region.  Multi-GPU: one process per GPU (torchrun), every rank runs its own
+sequences (weak scaling), one RCCL weight broadcast at start-up, no per-step collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def log(msg):
+    """Progress line (stderr + gpurun_out/bench_progress.log): long silent runs are killed as hung."""
+    line = f'[bench {time.strftime("%H:%M:%S")}] {msg}'
+    print(line, file=sys.stderr, flush=True)
+    try:
+        os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(REPO, 'gpurun_out', 'bench_progress.log'), 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+def host_cores():
+    """Usable host cores: affinity mask capped by the cgroup CPU quota (a GPU box hands out a
+    share of its cores; running 256 threads on a 16-core share is pathologically slow)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()
+            if q != 'max':
+                n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    env = os.environ.get('BDE_CPU_THREADS')
+    if env:
+        n = int(env)
+    return max(1, min(n, 64))
+
+
+def lstm_flops_per_launch(cfg, B, H, W, level):
+    """Algorithmic flops of ONE recurrent ConvLSTM step launch (both directions):
+    h-part of the gates conv, 2 * (4C) * C * 9 per pixel, plus ~20 flop/px/channel pointwise."""
+    C = cfg.enc_out(level)
+    hw = (H >> (level + 1)) * (W >> (level + 1))
+    return 2 * B * hw * (2.0 * 4 * C * C * 9 + 20.0 * C)
+
+
+def synth_voxels(T, H, W, sensor_hw, device, seed0=1000):
+    from bde2vid_amd.events import events_to_voxel_batch
+    from oracle.voxel_oracle import synthetic_events   # input generator only
+    sh, sw = sensor_hw
+    packs = [synthetic_events(sh * sw // 2, sh, sw, seed0 + t) for t in range(T)]
+    off = np.cumsum([0] + [len(p[0]) for p in packs])
+    cat = [torch.from_numpy(np.concatenate([p[k] for p in packs])) for k in range(4)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    grids = events_to_voxel_batch(*cat, off, 5, sensor_size=(sh, sw), device=device)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pt, pl = -(-(H - sh) // 2), -(-(W - sw) // 2)
+    out = torch.zeros((T, 1, 5, H, W), device=device)
+    out[:, 0, :, pt:pt + sh, pl:pl + sw] = grids
+    return out, int(off[-1]), dt
+
+
+def cpu_baseline(cfg, sd, H, W, T):
+    """CPU restatement (oracle) timed on the host cores: reported baseline, never the product."""
+    from oracle import bde2vid_oracle as O
+    from oracle.gen_golden import golden_inputs
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    xs = [{'events': torch.from_numpy(x)} for x in golden_inputs(T, 1, cfg.num_bins, H, W, 7)]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.forward(sd, cfg, xs)
+        dt = time.perf_counter() - t0
+    return dict(value=T / dt, unit='frames/s', cores=cores, kind='port',
+                sample=f'one oracle forward, T={T}, 5x{H}x{W}, torch {torch.__version__} CPU, {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--seq-len', type=int, default=16)
+    ap.add_argument('--height', type=int, default=180)
+    ap.add_argument('--width', type=int, default=240)
+    ap.add_argument('--batch', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from bde2vid_amd import canonical, _lib
+    from bde2vid_amd.dist import init_from_env, build_replicated_model, max_over_ranks, barrier
+    from bde2vid_amd.weights import formula_state_dict
+    from oracle.bde2vid_oracle import crop_params
+
+    log('start')
+    rank, world, local = init_from_env()
+    assert world == max(args.gpus, 1) or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    cfg = canonical()
+    sd_holder = {}
+
+    def get_sd():
+        sd_holder['sd'] = formula_state_dict(cfg)
+        return sd_holder['sd']
+    model = build_replicated_model(cfg, get_sd, device)
+    log('weights packed and resident')
+
+    cp = crop_params(args.width, args.height, cfg.num_encoders)
+    H, W, T, B = cp['hc'], cp['wc'], args.seq_len, args.batch
+    vox, n_events, vox_dt = synth_voxels(T, H, W, (args.height, args.width), device, seed0=1000 + 97 * rank)
+    if B > 1:
+        vox = vox.repeat(1, B, 1, 1, 1)
+    inputs = [{'events': vox[t]} for t in range(T)]
+    log(f'voxel grids ready ({n_events} events in {vox_dt*1e3:.1f} ms)')
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            model(inputs)
+            torch.cuda.synchronize(device)
+            log(f'warmup {i} done')
+        L = _lib.lib()
+        L.bde_profile_reset(model._h, 1)
+        barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(inputs)
+        torch.cuda.synchronize(device)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, device)
+    log(f'timed region done: {elapsed:.3f} s for {args.steps} steps')
+
+    if rank == 0:
+        import ctypes as C
+        frames = args.steps * T * B * world
+        ms = C.c_double()
+        cnt = C.c_int64()
+        level = 0
+        L.bde_profile_get(model._h, b'lstm0', C.byref(ms), C.byref(cnt))
+        fl = lstm_flops_per_launch(cfg, B, H, W, level)
+        avg_s = (ms.value / max(cnt.value, 1)) * 1e-3
+        achieved = fl / avg_s / 1e12 if avg_s > 0 else 0.0
+        out = {
+            'metric': 'reconstructed frames/sec at 5x240x180 voxels, seq_len=16',
+            'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BDE2VID.forward config A (5 bins, 32 ch, depths [4,0,6], 16 heads, D=3), '
+                                   f'{T} frames of 5x{args.height}x{args.width} (padded {H}x{W}), batch {B}, '
+                                   f'random-init formula weights, one independent sequence per step per GPU',
+                       'seq_len': T, 'height': args.height, 'width': args.width, 'batch': B,
+                       'parallelism': f'{world} replicas, sequences sharded, 1 RCCL weight broadcast'},
+            'roofline': {'kernel': 'conv_mfma_kernel<3,1,4,1,8,splitK,LSTM> (level-0 ConvLSTM step, both directions)',
+                         'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'launches': int(cnt.value), 'avg_us': avg_s * 1e6, 'flops_per_launch': fl},
+            'voxelize': {'events_per_s': n_events / vox_dt, 'events': n_events,
+                         'note': 'HIP scatter incl. H2D of the events; outside the timed region'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log(f'cpu baseline on {host_cores()} host cores ...')
+            out['cpu_baseline'] = cpu_baseline(cfg, sd_holder['sd'], H, W, T)
+        print(json.dumps(out))
+    barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -91,6 +91,12 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
  * (level output after attention), "dec<j>".  Layout [T][B][C][H][W]. */
 int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream);
 
+/* HIP-event timing of the tagged launches of subsequent bde_forward calls (bench.py's roofline):
+ * names "forward", "head", "enc_conv", "gates_x", "lstm<l>" (one span per recurrent step launch),
+ * "attn<l>", "decoder".  bde_profile_get synchronises on the recorded events. */
+int bde_profile_reset(bde_model* m, int32_t enable);
+int bde_profile_get(bde_model* m, const char* name, double* total_ms, int64_t* count);
+
 /* Event -> voxel grid.  xs, ys, ts, ps: device fp32 [N] (ts sorted ascending);
  * grid: device fp32 [num_bins][H][W], overwritten.  oob_count (device int32, may be NULL) receives
  * the number of events whose pixel index fell outside the sensor (the reference raises there). */
