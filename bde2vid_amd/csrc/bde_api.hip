@@ -18,6 +18,7 @@
 #include "attn.h"
 #include "common.h"
 #include "conv_mfma.h"
+#include "pw_gemm.h"
 #include "voxel.h"
 
 namespace bde {
@@ -62,6 +63,43 @@ static int add2(const float* a, const float* b, float* o, long n, hipStream_t s)
     return BDE_OK;
 }
 
+// Bilinear x2 (align_corners=False) of (a + b): the input of UpsampleConvLayer's conv
+// (submodules.py:138) with the skip_sum (V5.py:289-293) folded in.  src = dst/2 - 0.25 clamped at 0:
+// even dst 2k -> 0.25*in[k-1] + 0.75*in[k]; odd dst 2k+1 -> 0.75*in[k] + 0.25*in[k+1]; edges clamp.
+__global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ out, int Hs, int Ws, long planes) {
+    const int Wo = 2 * Ws, Ho = 2 * Hs;
+    const long total = planes * Ho * Wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        const long t = i / Wo;
+        const int y = (int)(t % Ho);
+        const long pl = t / Ho;
+        int ya = max((y - 1) >> 1, 0), yb = min((y + 1) >> 1, Hs - 1);
+        int xa = max((x - 1) >> 1, 0), xb = min((x + 1) >> 1, Ws - 1);
+        if (y == 0) ya = yb = 0;
+        if (x == 0) xa = xb = 0;
+        float wyb = (y & 1) ? 0.25f : 0.75f, wxb = (x & 1) ? 0.25f : 0.75f;
+        if (ya == yb) wyb = 1.f;
+        if (xa == xb) wxb = 1.f;
+        const float wya = 1.f - wyb, wxa = 1.f - wxb;
+        const float* pa = a + pl * Hs * Ws;
+        float v00 = pa[ya * Ws + xa], v01 = pa[ya * Ws + xb], v10 = pa[yb * Ws + xa], v11 = pa[yb * Ws + xb];
+        if (b) {
+            const float* pb = b + pl * Hs * Ws;
+            v00 += pb[ya * Ws + xa]; v01 += pb[ya * Ws + xb]; v10 += pb[yb * Ws + xa]; v11 += pb[yb * Ws + xb];
+        }
+        out[i] = wya * (wxa * v00 + wxb * v01) + wyb * (wxa * v10 + wxb * v11);
+    }
+}
+static int upsample2x_sum(const float* a, const float* b, float* out, int Hs, int Ws, long planes, hipStream_t s) {
+    const long total = planes * 4 * Hs * Ws;
+    long blocks = std::min<long>(cdivl(total, 256), 8192);
+    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, Hs, Ws, planes);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
 // predI (1x1 conv C->1) on (x + head) followed by the output activation (V5.py:195-197).
 __global__ __launch_bounds__(256) void pred_kernel(const float* __restrict__ x, const float* __restrict__ head,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
@@ -84,61 +122,6 @@ __global__ __launch_bounds__(256) void pred_kernel(const float* __restrict__ x, 
 // ------------------------------------------------------------------------------------------
 // packed layers
 // ------------------------------------------------------------------------------------------
-enum Variant {
-    V_NONE = 0,
-    V_K5S1_M1N2, V_K5S1_M2N2, V_K5S2_M1N1, V_K5S2_M2N1, V_K5UP_M1N2, V_K5UP_M2N2,
-    V_K3S1_M1N2, V_K3S1_M2N2, V_K3S2_M1N1, V_K3S2_M2N1, V_K3UP_M1N2, V_K3UP_M2N2,
-    V_K3_LSTM,
-    V_K1_M1N2, V_K1_M2N2, V_K1SK_M1N1, V_K1SK_M2N1
-};
-
-struct VariantInfo { int KS, S, MT, CK; bool splitk; };
-static VariantInfo variant_info(Variant v) {
-    switch (v) {
-        case V_K5S1_M1N2: return {5, 1, 1, 8, false};
-        case V_K5S1_M2N2: return {5, 1, 2, 8, false};
-        case V_K5S2_M1N1: return {5, 2, 1, 8, false};
-        case V_K5S2_M2N1: return {5, 2, 2, 8, false};
-        case V_K5UP_M1N2: return {5, 1, 1, 8, false};
-        case V_K5UP_M2N2: return {5, 1, 2, 8, false};
-        case V_K3S1_M1N2: return {3, 1, 1, 8, false};
-        case V_K3S1_M2N2: return {3, 1, 2, 8, false};
-        case V_K3S2_M1N1: return {3, 2, 1, 8, false};
-        case V_K3S2_M2N1: return {3, 2, 2, 8, false};
-        case V_K3UP_M1N2: return {3, 1, 1, 8, false};
-        case V_K3UP_M2N2: return {3, 1, 2, 8, false};
-        case V_K3_LSTM:   return {3, 1, 4, 8, true};
-        case V_K1_M1N2:   return {1, 1, 1, 16, false};
-        case V_K1_M2N2:   return {1, 1, 2, 16, false};
-        case V_K1SK_M1N1: return {1, 1, 1, 16, true};
-        case V_K1SK_M2N1: return {1, 1, 2, 16, true};
-        default: return {0, 0, 0, 0, false};
-    }
-}
-
-static int launch_variant(Variant v, const ConvArgs& a, int G, hipStream_t s) {
-    switch (v) {
-        case V_K5S1_M1N2: return conv_launch_t<5, 1, 1, 2, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K5S1_M2N2: return conv_launch_t<5, 1, 2, 2, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K5S2_M1N1: return conv_launch_t<5, 2, 1, 1, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K5S2_M2N1: return conv_launch_t<5, 2, 2, 1, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K5UP_M1N2: return conv_launch_t<5, 1, 1, 2, 8, true, false, EPI_GENERIC>(a, G, s);
-        case V_K5UP_M2N2: return conv_launch_t<5, 1, 2, 2, 8, true, false, EPI_GENERIC>(a, G, s);
-        case V_K3S1_M1N2: return conv_launch_t<3, 1, 1, 2, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K3S1_M2N2: return conv_launch_t<3, 1, 2, 2, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K3S2_M1N1: return conv_launch_t<3, 2, 1, 1, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K3S2_M2N1: return conv_launch_t<3, 2, 2, 1, 8, false, false, EPI_GENERIC>(a, G, s);
-        case V_K3UP_M1N2: return conv_launch_t<3, 1, 1, 2, 8, true, false, EPI_GENERIC>(a, G, s);
-        case V_K3UP_M2N2: return conv_launch_t<3, 1, 2, 2, 8, true, false, EPI_GENERIC>(a, G, s);
-        case V_K3_LSTM:   return conv_launch_t<3, 1, 4, 1, 8, false, true, EPI_LSTM>(a, G, s);
-        case V_K1_M1N2:   return conv_launch_t<1, 1, 1, 2, 16, false, false, EPI_GENERIC>(a, G, s);
-        case V_K1_M2N2:   return conv_launch_t<1, 1, 2, 2, 16, false, false, EPI_GENERIC>(a, G, s);
-        case V_K1SK_M1N1: return conv_launch_t<1, 1, 1, 1, 16, false, true, EPI_GENERIC>(a, G, s);
-        case V_K1SK_M2N1: return conv_launch_t<1, 1, 2, 1, 16, false, true, EPI_GENERIC>(a, G, s);
-        default: return fail(BDE_ERR_STATE, "conv variant %d not built", (int)v);
-    }
-}
-
 // A dense host-side layer before packing: rows x (Cin*KS*KS), row-major [row][ci][ky][kx].
 struct DenseLayer {
     int rows = 0, Cin = 0, KS = 1;
@@ -147,8 +130,8 @@ struct DenseLayer {
 
 // One packed layer inside the device arena (offsets in floats).
 struct PackedLayer {
-    Variant v = V_NONE;
-    int Cin = 0, Cout = 0, KS = 1, nchunks = 0, ntiles = 0;
+    int Cin = 0, Cout = 0, KS = 1, CK = 8, nchunks = 0, ntiles = 0;
+    bool lstm = false;
     long w_off = -1, b_off = -1, s_off = -1;   // weights / bias / lnsum
     long w_sz = 0;                              // floats of one group's packed weights
     int G = 1;                                  // groups packed back to back (fwd, bwd)
@@ -183,35 +166,21 @@ static void pack_rows(const DenseLayer& d, const std::vector<int>& rowmap, int C
                 }
 }
 
-static Variant pick_variant(int KS, int stride, bool up2, bool splitk, bool lstm, int Cout) {
-    const bool m2 = Cout > 32;
-    if (lstm) return V_K3_LSTM;
-    if (KS == 1) return splitk ? (m2 ? V_K1SK_M2N1 : V_K1SK_M1N1) : (m2 ? V_K1_M2N2 : V_K1_M1N2);
-    if (KS == 5) {
-        if (up2) return m2 ? V_K5UP_M2N2 : V_K5UP_M1N2;
-        if (stride == 2) return m2 ? V_K5S2_M2N1 : V_K5S2_M1N1;
-        return m2 ? V_K5S1_M2N2 : V_K5S1_M1N2;
-    }
-    if (KS == 3) {
-        if (up2) return m2 ? V_K3UP_M2N2 : V_K3UP_M1N2;
-        if (stride == 2) return m2 ? V_K3S2_M2N1 : V_K3S2_M1N1;
-        return m2 ? V_K3S1_M2N2 : V_K3S1_M1N2;
-    }
-    return V_NONE;
-}
-
 // Append G dense layers (same shape) to the arena as one grouped packed layer.
-static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, Variant v, bool lstm) {
+// Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
+// four (one per wave); pointwise layers CK = 16 in groups of eight (any pw_gemm split-K factor).
+static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, bool lstm) {
     const DenseLayer& d0 = *groups[0];
-    VariantInfo vi = variant_info(v);
     PackedLayer pl;
-    pl.v = v;
     pl.Cin = d0.Cin;
     pl.Cout = d0.rows;
     pl.KS = d0.KS;
+    pl.lstm = lstm;
     pl.G = (int)groups.size();
-    pl.nchunks = cdiv(d0.Cin, vi.CK);
-    if (vi.splitk) pl.nchunks = cdiv(pl.nchunks, 4) * 4;
+    pl.CK = (lstm || d0.KS == 1) ? 16 : 8;
+    pl.nchunks = cdiv(d0.Cin, pl.CK);
+    if (lstm) pl.nchunks = cdiv(pl.nchunks, 4) * 4;
+    if (d0.KS == 1) pl.nchunks = cdiv(pl.nchunks, 8) * 8;
     std::vector<int> rowmap;
     if (lstm) {
         // packed tile (cb*4 + gate) holds gate rows gate*Ch + cb*32 .. +32  (conv_mfma.h EPI_LSTM)
@@ -222,19 +191,19 @@ static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& g
                 for (int j = 0; j < 32; ++j)
                     if (cb * 32 + j < Ch) rowmap[((size_t)cb * 4 + gate) * 32 + j] = gate * Ch + cb * 32 + j;
     } else {
-        const int rows_pad = cdiv(d0.rows, 32 * vi.MT) * 32 * vi.MT;
+        const int rows_pad = cdiv(d0.rows, 64) * 64;        // MT (1 or 2 tiles per wave) is chosen at launch
         rowmap.assign(rows_pad, -1);
         for (int r = 0; r < d0.rows; ++r) rowmap[r] = r;
     }
     pl.ntiles = (int)rowmap.size() / 32;
-    pl.w_sz = (long)pl.ntiles * pl.nchunks * d0.KS * d0.KS * (vi.CK / 2) * 64;
+    pl.w_sz = (long)pl.ntiles * pl.nchunks * d0.KS * d0.KS * (pl.CK / 2) * 64;
     pl.w_off = ar.alloc(pl.w_sz * pl.G);
     pl.b_off = ar.alloc((long)d0.rows * pl.G);
     const bool ln = !d0.lnsum.empty();
     if (ln) pl.s_off = ar.alloc((long)d0.rows * pl.G);
     for (int g = 0; g < pl.G; ++g) {
         const DenseLayer& d = *groups[g];
-        pack_rows(d, rowmap, vi.CK, pl.nchunks, ar.host.data() + pl.w_off + g * pl.w_sz);
+        pack_rows(d, rowmap, pl.CK, pl.nchunks, ar.host.data() + pl.w_off + g * pl.w_sz);
         std::copy(d.bias.begin(), d.bias.end(), ar.host.begin() + pl.b_off + (long)g * d0.rows);
         if (ln) std::copy(d.lnsum.begin(), d.lnsum.end(), ar.host.begin() + pl.s_off + (long)g * d0.rows);
     }
@@ -260,6 +229,7 @@ struct Workspace {
     float* out = nullptr;
     std::vector<float*> xenc, gx, hseq, cst, merged, kvun, kvref, dec;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
+    float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     void release() {
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
@@ -383,7 +353,7 @@ static int build_packed(bde_model* m) {
     {
         DenseLayer d;
         BDE_TRY(dense_conv(m, "head.conv2d.weight", "head.conv2d.bias", bc, c.num_bins, 0, c.num_bins, ks, true, &d));
-        m->head = pack_layer(ar, {&d}, pick_variant(ks, 1, false, false, false, bc), false);
+        m->head = pack_layer(ar, {&d}, false);
     }
     const char* dirs[2] = {"forward_encoder", "backward_encoder"};
     for (int l = 0; l < L; ++l) {
@@ -398,9 +368,9 @@ static int build_packed(bde_model* m) {
             BDE_TRY(dense_conv(m, p + "recurrent_block.Gates.weight", p + "recurrent_block.Gates.bias", 4 * co, 2 * co, co,
                                co, 3, false, &gh[d]));
         }
-        m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, pick_variant(ks, 2, false, false, false, co), false);
-        m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, pick_variant(3, 1, false, false, false, 4 * co), false);
-        m->lstm[l] = pack_layer(ar, {&gh[0], &gh[1]}, V_K3_LSTM, true);
+        m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, false);
+        m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, false);
+        m->lstm[l] = pack_layer(ar, {&gh[0], &gh[1]}, true);
     }
     const int D = c.frame_num, heads = c.num_heads;
     const int tbl_rows = (2 * D - 1) * 13 * 13;
@@ -451,7 +421,7 @@ static int build_packed(bde_model* m) {
             fold_ln_rows(wq, biq, gq, bq, C, C, scale, &qkv, 0);
             fold_ln_rows(wkv, bikv, gkv, bkv, 2 * C, C, 1.f, &qkv, C);
             fold_ln_rows(wkv, bikv, gkv, bkv, 2 * C, C, 1.f, &kvall, i * 2 * C);
-            ab.qkv = pack_layer(ar, {&qkv}, pick_variant(1, 1, false, true, false, 3 * C), false);
+            ab.qkv = pack_layer(ar, {&qkv}, false);
             // K|V of an all-zero token: LayerNorm(0) = beta  ->  W beta + b  (DTransformer.py:183-190)
             ab.kvpad_off = ar.alloc(2 * C);
             std::copy(qkv.bias.begin() + C, qkv.bias.end(), ar.host.begin() + ab.kvpad_off);
@@ -472,28 +442,28 @@ static int build_packed(bde_model* m) {
             proj.rows = C; proj.Cin = C; proj.KS = 1;
             proj.w.assign(wp, wp + (size_t)C * C);
             proj.bias.assign(bp, bp + C);
-            ab.proj = pack_layer(ar, {&proj}, pick_variant(1, 1, false, true, false, C), false);
+            ab.proj = pack_layer(ar, {&proj}, false);
             DenseLayer fc1;
             fc1.rows = hid; fc1.Cin = C; fc1.KS = 1;
             fc1.w.resize((size_t)hid * C);
             fc1.bias.resize(hid);
             fc1.lnsum.resize(hid);
             fold_ln_rows(w1, b1, g2, b2, hid, C, 1.f, &fc1, 0);
-            ab.fc1 = pack_layer(ar, {&fc1}, pick_variant(1, 1, false, true, false, hid), false);
+            ab.fc1 = pack_layer(ar, {&fc1}, false);
             DenseLayer fc2;
             fc2.rows = C; fc2.Cin = hid; fc2.KS = 1;
             fc2.w.assign(w2, w2 + (size_t)C * hid);
             fc2.bias.assign(b2b, b2b + C);
-            ab.fc2 = pack_layer(ar, {&fc2}, pick_variant(1, 1, false, true, false, C), false);
+            ab.fc2 = pack_layer(ar, {&fc2}, false);
         }
-        al.kvall = pack_layer(ar, {&kvall}, pick_variant(1, 1, false, false, false, kvall.rows), false);
+        al.kvall = pack_layer(ar, {&kvall}, false);
     }
     for (int j = 0; j < L; ++j) {
         const int cin = m->cout(L - 1 - j), cout = m->cin(L - 1 - j);
         DenseLayer d;
         std::string p = "decoders." + std::to_string(j) + ".1.conv2d.";
         BDE_TRY(dense_conv(m, p + "weight", p + "bias", cout, cin, 0, cin, ks, true, &d));
-        m->dec[j] = pack_layer(ar, {&d}, pick_variant(ks, 1, true, false, false, cout), false);
+        m->dec[j] = pack_layer(ar, {&d}, false);
     }
     {
         const float *w, *b;
@@ -525,12 +495,10 @@ static int upload(bde_model* m) {
 struct ConvCall {
     const PackedLayer* pl = nullptr;
     const float* in = nullptr;
-    const float* in2 = nullptr;
     float* out = nullptr;
     const float* res1 = nullptr;
     const float* res2 = nullptr;
-    int N = 1, Hs = 0, Ws = 0;   // stored input dims
-    bool up2 = false;
+    int N = 1, Hs = 0, Ws = 0;   // input dims
     int stride = 1;
     int act = ACT_NONE;
     long in_gs = 0, out_gs = 0;  // group strides (0 = shared input)
@@ -543,7 +511,6 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     ConvArgs a;
     memset(&a, 0, sizeof a);
     a.in = cc.in;
-    a.in2 = cc.in2;
     a.wpk = m->P(pl.w_off);
     a.bias = m->P(pl.b_off);
     a.lnsum = pl.s_off >= 0 ? m->P(pl.s_off) : nullptr;
@@ -554,8 +521,8 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.Cin = pl.Cin;
     a.Hs = cc.Hs;
     a.Ws = cc.Ws;
-    a.Hin = cc.up2 ? 2 * cc.Hs : cc.Hs;
-    a.Win = cc.up2 ? 2 * cc.Ws : cc.Ws;
+    a.Hin = cc.Hs;
+    a.Win = cc.Ws;
     a.Cout = pl.Cout;
     const int pad = pl.KS / 2;
     a.Ho = (a.Hin + 2 * pad - pl.KS) / cc.stride + 1;
@@ -566,15 +533,15 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.mask_pt = cc.mask_pt;
     a.mask_pl = cc.mask_pl;
     const long in_fs = (long)pl.Cin * cc.Hs * cc.Ws, out_fs = (long)pl.Cout * a.Ho * a.Wo;
-    a.in_ns = a.in2_ns = in_fs;
+    a.in_ns = in_fs;
     a.out_ns = a.res1_ns = a.res2_ns = out_fs;
     a.in_gs = cc.in_gs;
-    a.in2_gs = cc.in_gs;
     a.out_gs = cc.out_gs;
     a.res1_gs = a.res2_gs = cc.out_gs;
     a.w_gs = pl.w_sz;
     a.bias_gs = pl.Cout;
-    return launch_variant(pl.v, a, pl.G, s);
+    if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
+    return conv_launch_auto(pl.KS, cc.stride, a, pl.G, s);
 }
 
 // 1x1 conv over flattened [C][HW] planes
@@ -635,6 +602,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         const int j = L - 1 - l;   // decoder j writes the map of level (L-1-j)'s input resolution
         BDE_TRY(ws_alloc(ws, &ws.dec[j], TB * m->cin(l) * (long)(H >> l) * (W >> l)));
     }
+    BDE_TRY(ws_alloc(ws, &ws.up, TB * m->cout(0) * (long)H * W));   // dec L-1: cout(0) channels at full resolution
     if (max_attn > 0) {
         BDE_TRY(ws_alloc(ws, &ws.qkv, 3 * max_attn));
         BDE_TRY(ws_alloc(ws, &ws.ao, max_attn));
@@ -720,7 +688,7 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         {
             static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
             ProfScope ps(m, names[l], s);
-            BDE_TRY(launch_variant(pl.v, a, 2, s));
+            BDE_TRY(lstm_launch(a, s));
         }
     }
     return BDE_OK;
@@ -814,6 +782,22 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
     return BDE_OK;
 }
 
+// UpsampleConvLayer of decoder j on N frames [Cin][Hs][Ws] (+ skip): upsample kernel, then a plain conv.
+static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
+                       hipStream_t s) {
+    const PackedLayer& pl = m->dec[j];
+    BDE_TRY(upsample2x_sum(in, skip, m->ws.up, Hs, Ws, (long)N * pl.Cin, s));
+    ConvCall d;
+    d.pl = &pl;
+    d.in = m->ws.up;
+    d.out = out;
+    d.N = N;
+    d.Hs = 2 * Hs;
+    d.Ws = 2 * Ws;
+    d.act = ACT_RELU6;
+    return run_conv(m, d, s);
+}
+
 static int check_dims(const bde_model* m, int T, int B, int H, int W) {
     const bde_config& c = m->cfg;
     BDE_REQUIRE(m->finalized, "weights are not finalized");
@@ -868,17 +852,8 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     const float* x = ws.merged[L - 1];
     for (int j = 0; j < L; ++j) {
         const int l = L - 1 - j;
-        ConvCall d;
-        d.pl = &m->dec[j];
-        d.in = x;
-        d.in2 = ws.merged[l];
-        d.out = ws.dec[j];
-        d.N = (int)TB;
-        d.Hs = H >> (l + 1);
-        d.Ws = W >> (l + 1);
-        d.up2 = true;
-        d.act = ACT_RELU6;
-        { ProfScope ps(m, "decoder", s); BDE_TRY(run_conv(m, d, s)); }
+        { ProfScope ps(m, "decoder", s);
+          BDE_TRY(run_decoder(m, j, x, ws.merged[l], ws.dec[j], (int)TB, H >> (l + 1), W >> (l + 1), s)); }
         x = ws.dec[j];
     }
     {
@@ -1138,9 +1113,9 @@ int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float*
 int bde_op_decoder(bde_model* m, int32_t j, const float* in, const float* skip, int32_t N, int32_t H, int32_t W,
                    float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out && j >= 0 && j < m->L, "bad argument");
-    ConvCall c;
-    c.pl = &m->dec[j]; c.in = in; c.in2 = skip; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.up2 = true; c.act = ACT_RELU6;
-    return run_conv(m, c, (hipStream_t)stream);
+    const int L = m->L, l = L - 1 - j;
+    BDE_TRY(ensure_workspace(m, N, 1, H << (l + 1), W << (l + 1)));
+    return run_decoder(m, j, in, skip, out, N, H, W, (hipStream_t)stream);
 }
 
 int bde_op_pred(bde_model* m, const float* in, const float* head, int32_t N, int32_t H, int32_t W, float* out,

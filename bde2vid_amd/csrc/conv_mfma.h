@@ -56,6 +56,9 @@ struct ConvArgs {
     // dilated-window coverage mask (DTransformer.py:79-82): pixels the fold never writes get
     // res1+res2 only.  mask_w = map width used to recover (y,x) from p; 0 = off.
     int mask_w, mask_pt, mask_pl;
+    // >0: pixel tiles are aligned to image rows (row_tiles tiles of BN pixels per row, the last one
+    // partial) so a tile never straddles two rows and its halo is KS rows x (BN*S+KS-1) columns.
+    int row_tiles;
     // ---- EPI_LSTM (group = direction) ---------------------------------------------------
     const float* gx;     // [G][N][4*Ch][HW]  x-part of the gates incl. bias
     float* cstate;       // [G][N][Ch][HW]    cell state, updated in place
@@ -74,22 +77,72 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // Row of accumulator register r inside a 32x32 tile (cdna_hip_programming.md §3).
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-template <int KS, int STRIDE, int MT, int NT, int CK, bool UP2, bool SPLITK, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// Shared epilogue of the generic contractions: LayerNorm fold, bias, activation, dilated-window
+// coverage mask, residual adds, NCHW store (lane = pixel -> 128-B segments).
+template <int MT, int NT, int RPW>
+__device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float (&fin)[MT][NT][RPW], const int (&pix)[NT],
+                                                 int r0, int lane, int g, int n, int HW, int p_end, bool want_ln,
+                                                 const float (&mu)[NT], const float (&rstd)[NT]) {
+    float* outb = a.out + g * a.out_gs + n * a.out_ns;
+    const float* r1 = a.res1 ? a.res1 + g * a.res1_gs + n * a.res1_ns : nullptr;
+    const float* r2 = a.res2 ? a.res2 + g * a.res2_gs + n * a.res2_ns : nullptr;
+    const float* biasg = a.bias + g * a.bias_gs;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = pix[t];
+        if (p >= p_end) continue;
+        bool covered = true;
+        if (a.mask_w > 0) {
+            int y = p / a.mask_w, x = p - y * a.mask_w;
+            int rr = y + a.mask_pt, cc = x + a.mask_pl;
+            covered = !((rr < 7 && (rr & 1)) || (cc < 7 && (cc & 1)));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int cob = (blockIdx.y * MT + m) * 32;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int co = cob + acc_row(r0 + rr, lane);
+                if (co >= a.Cout) continue;
+                float v = fin[m][t][rr];
+                if (want_ln) v = rstd[t] * (v - mu[t] * a.lnsum[co]);
+                v = act_apply(v + biasg[co], a.act);
+                if (!covered) v = 0.f;
+                const long o = (long)co * HW + p;
+                if (r1) v += r1[o];
+                if (r2) v += r2[o];
+                outb[o] = v;
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int MT, int NT, int CK, bool SPLITK, int EPI, int MAXI>
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int PAIRS = CK / 2;
     constexpr int WN = SPLITK ? 1 : 4;        // waves along the pixel axis
     constexpr int BN = WN * NT * 32;          // pixels per block
     constexpr int STAGE_C = SPLITK ? 4 * CK : CK;   // channels staged per barrier pair
+    constexpr int CG = SPLITK ? 8 : 1;        // channel groups of the staging work items
+    constexpr int CPI = STAGE_C / CG;         // channels per work item
     extern __shared__ __align__(16) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.z;
     const int g = z / a.N, n = z - g * a.N;
     const int HW = a.Ho * a.Wo;
-    const int p0 = blockIdx.x * BN;
-    const int p_last = min(p0 + BN, HW) - 1;
+    int p0, p_end;
+    if (a.row_tiles > 0) {
+        const int yy = blockIdx.x / a.row_tiles, xt = blockIdx.x - yy * a.row_tiles;
+        p0 = yy * a.Wo + xt * BN;
+        p_end = min(p0 + BN, (yy + 1) * a.Wo);
+    } else {
+        p0 = blockIdx.x * BN;
+        p_end = min(p0 + BN, HW);
+    }
+    const int p_last = p_end - 1;
     const int y_first = p0 / a.Wo, y_last = p_last / a.Wo;
     const bool one_row = (y_first == y_last);
     const int x_first = p0 - y_first * a.Wo;
@@ -126,64 +179,59 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const bool skip_mac = (EPI == EPI_LSTM) && a.first;
     if (!skip_mac) {
         const float* inb = a.in + g * a.in_gs + n * a.in_ns;
-        const float* in2b = a.in2 ? a.in2 + g * a.in2_gs + n * a.in2_ns : nullptr;
         const float* wg = a.wpk + g * a.w_gs;
         const long HsWs = (long)a.Hs * a.Ws;
         const int tile_elems = R * IW;
-        const float inv_iw = 1.0f / (float)IW;
         const int nstages = SPLITK ? a.nchunks / 4 : a.nchunks;
-        for (int st = 0; st < nstages; ++st) {
-            const int c0 = st * STAGE_C;
-            __syncthreads();   // previous stage fully consumed
-            // ---- stage STAGE_C input channels of the halo tile into LDS ------------------
-            for (int e = tid; e < tile_elems; e += 256) {
-                int r = (int)(((float)e + 0.5f) * inv_iw);
-                int col = e - r * IW;
-                int iy = iy0 + r, ix = ix0 + col;
-                bool ok = (iy >= 0) && (iy < a.Hin) && (ix >= 0) && (ix < a.Win);
-                float* dst = lds + e;
-                if constexpr (!UP2) {
-                    const long off = (long)iy * a.Ws + ix;
-#pragma unroll 8
-                    for (int ci = 0; ci < STAGE_C; ++ci) {
-                        float v = 0.f;
-                        if (ok && (c0 + ci) < a.Cin) {
-                            v = inb[(long)(c0 + ci) * HsWs + off];
-                            if (in2b) v += in2b[(long)(c0 + ci) * HsWs + off];
-                        }
-                        dst[ci * PS] = v;
-                    }
-                } else {
-                    // bilinear x2, align_corners=False: src = (dst+0.5)/2-0.5 clamped at 0;
-                    // even dst -> 0.25*in[i-1]+0.75*in[i], odd -> 0.75*in[i]+0.25*in[i+1], edges clamp
-                    int ya = max((iy - 1) >> 1, 0), yb = min((iy + 1) >> 1, a.Hs - 1);
-                    int xa = max((ix - 1) >> 1, 0), xb = min((ix + 1) >> 1, a.Ws - 1);
-                    if (iy == 0) ya = yb = 0;
-                    if (ix == 0) xa = xb = 0;
-                    float wyb = (iy & 1) ? 0.25f : 0.75f, wxb = (ix & 1) ? 0.25f : 0.75f;
-                    if (iy == 0 || ya == yb) wyb = 1.f;   // clamped edge: both taps coincide
-                    if (ix == 0 || xa == xb) wxb = 1.f;
-                    // torch: lambda1 (weight of the upper/right tap) = frac(src); for odd dst 0.25, even 0.75
-                    float wya = 1.f - wyb, wxa = 1.f - wxb;
-                    const long o00 = (long)ya * a.Ws + xa, o01 = (long)ya * a.Ws + xb;
-                    const long o10 = (long)yb * a.Ws + xa, o11 = (long)yb * a.Ws + xb;
-#pragma unroll 4
-                    for (int ci = 0; ci < STAGE_C; ++ci) {
-                        float v = 0.f;
-                        if (ok && (c0 + ci) < a.Cin) {
-                            const float* s = inb + (long)(c0 + ci) * HsWs;
-                            float v00 = s[o00], v01 = s[o01], v10 = s[o10], v11 = s[o11];
-                            if (in2b) {
-                                const float* s2p = in2b + (long)(c0 + ci) * HsWs;
-                                v00 += s2p[o00]; v01 += s2p[o01]; v10 += s2p[o10]; v11 += s2p[o11];
-                            }
-                            v = wya * (wxa * v00 + wxb * v01) + wyb * (wxa * v10 + wxb * v11);
-                        }
-                        dst[ci * PS] = v;
-                    }
-                }
+        // ---- staging work items of this thread: (tile element, channel group), fixed for all
+        //      stages.  goff < 0: zero padding; lde < 0: no work item.
+        int goff[MAXI];
+        int lde[MAXI], cgi[MAXI];
+        {
+            const float inv_iw = 1.0f / (float)IW;
+            const float inv_te = 1.0f / (float)tile_elems;
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) {
+                const int wi = tid + it * 256;
+                const int cg = (CG == 1) ? 0 : (int)(((float)wi + 0.5f) * inv_te);
+                const int e = wi - cg * tile_elems;
+                const int r = (int)(((float)e + 0.5f) * inv_iw);
+                const int col = e - r * IW;
+                const int iy = iy0 + r, ix = ix0 + col;
+                const bool in_img = (iy >= 0) && (iy < a.Hin) && (ix >= 0) && (ix < a.Win);
+                const bool item = wi < tile_elems * CG;
+                lde[it] = item ? e : -1;
+                cgi[it] = cg;
+                goff[it] = (item && in_img) ? iy * a.Ws + ix : -1;
             }
+        }
+        float sv[MAXI][CPI];
+        auto stage_load = [&](int st) {
+            const int c0 = st * STAGE_C;
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it)
+#pragma unroll
+                for (int j = 0; j < CPI; ++j) {
+                    const int c = c0 + cgi[it] + j * CG;
+                    sv[it][j] = (goff[it] >= 0 && c < a.Cin) ? inb[(long)c * HsWs + goff[it]] : 0.f;
+                }
+        };
+        auto stage_store = [&]() {
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it)
+                if (lde[it] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < CPI; ++j) lds[lde[it] + (cgi[it] + j * CG) * PS] = sv[it][j];
+                }
+        };
+        // software pipeline (register staged, cdna_hip_programming.md T14): the global loads of
+        // stage s+1 are issued before the MFMA loop of stage s and land in LDS after it.
+        stage_load(0);
+        for (int st = 0; st < nstages; ++st) {
+            __syncthreads();   // previous stage fully consumed
+            stage_store();
             __syncthreads();
+            if (st + 1 < nstages) stage_load(st + 1);
             // ---- contraction over this stage's channels ---------------------------------
             const int chunk = SPLITK ? st * 4 + wave : st;
             const float* ldsw = lds + (SPLITK ? wave * CK * PS : 0);
@@ -310,38 +358,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     // ---- epilogue ----------------------------------------------------------------------------
     if constexpr (EPI == EPI_GENERIC) {
-        float* outb = a.out + g * a.out_gs + n * a.out_ns;
-        const float* r1 = a.res1 ? a.res1 + g * a.res1_gs + n * a.res1_ns : nullptr;
-        const float* r2 = a.res2 ? a.res2 + g * a.res2_gs + n * a.res2_ns : nullptr;
-        const float* biasg = a.bias + g * a.bias_gs;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int p = pix[t];
-            if (p >= HW) continue;
-            bool covered = true;
-            if (a.mask_w > 0) {
-                int y = p / a.mask_w, x = p - y * a.mask_w;
-                int rr = y + a.mask_pt, cc = x + a.mask_pl;
-                covered = !((rr < 7 && (rr & 1)) || (cc < 7 && (cc & 1)));
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int cob = (blockIdx.y * MT + m) * 32;
-#pragma unroll
-                for (int rr = 0; rr < RPW; ++rr) {
-                    const int co = cob + acc_row(r0 + rr, lane);
-                    if (co >= a.Cout) continue;
-                    float v = fin[m][t][rr];
-                    if (want_ln) v = rstd[t] * (v - mu[t] * a.lnsum[co]);
-                    v = act_apply(v + biasg[co], a.act);
-                    if (!covered) v = 0.f;
-                    const long o = (long)co * HW + p;
-                    if (r1) v += r1[o];
-                    if (r2) v += r2[o];
-                    outb[o] = v;
-                }
-            }
-        }
+        generic_epilogue<MT, NT, RPW>(a, fin, pix, r0, lane, g, n, HW, p_end, want_ln, mu, rstd);
     } else {
         // ConvLSTM pointwise (submodules.py:320-332): tiles m = gate i,f,o,g of the same 32 hidden
         // channels; acc holds W_h * h_prev, gx holds W_x * x + bias.
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int p = pix[t];
-            if (p >= HW) continue;
+            if (p >= p_end) continue;
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
                 const int hc = blockIdx.y * 32 + acc_row(r0 + rr, lane);
@@ -382,11 +399,15 @@ struct ConvGeom {
     int epi;
 };
 
-// Exact LDS requirement: max over blocks of (channels staged) * R * IW floats (+ split-K scratch).
-static inline size_t conv_lds_bytes(const ConvGeom& gm, int Win, int Ho, int Wo, bool ln) {
+// Largest halo tile (R*IW elements of one channel) over the blocks of a launch.
+static inline long conv_tile_elems(const ConvGeom& gm, int Win, int Ho, int Wo, int row_tiles) {
     const int PAD = gm.KS / 2;
     const int BN = (gm.splitk ? 1 : 4) * gm.NT * 32;
     const int HW = Ho * Wo;
+    if (row_tiles > 0) {
+        const int npx = BN < Wo ? BN : Wo;
+        return (long)gm.KS * ((npx - 1) * gm.STRIDE + gm.KS);
+    }
     long best = 0;
     for (int p0 = 0; p0 < HW; p0 += BN) {
         int pl = (p0 + BN < HW ? p0 + BN : HW) - 1;
@@ -396,20 +417,33 @@ static inline size_t conv_lds_bytes(const ConvGeom& gm, int Win, int Ho, int Wo,
         long e = (long)R * IW;
         if (e > best) best = e;
     }
-    long stage = (long)(gm.splitk ? 4 * gm.CK : gm.CK) * best;
+    return best;
+}
+
+static inline size_t conv_lds_bytes(const ConvGeom& gm, long tile_elems, bool ln) {
+    long stage = (long)(gm.splitk ? 4 * gm.CK : gm.CK) * tile_elems;
     long red = gm.splitk ? (long)gm.MT * gm.NT * 1024 + (ln ? 4 * gm.NT * 128 : 0) : 0;
     long fl = stage > red ? stage : red;
     return (size_t)fl * sizeof(float);
 }
 
-template <int KS, int STRIDE, int MT, int NT, int CK, bool UP2, bool SPLITK, int EPI>
+// staging work items per thread for a tile
+static inline int conv_stage_items(const ConvGeom& gm, long tile_elems) {
+    return (int)((tile_elems * (gm.splitk ? 8 : 1) + 255) / 256);
+}
+
+template <int KS, int STRIDE, int MT, int NT, int CK, bool SPLITK, int EPI, int MAXI>
 static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
-    ConvGeom gm{KS, STRIDE, MT, NT, CK, UP2, SPLITK, EPI};
-    const size_t lds = conv_lds_bytes(gm, a.Win, a.Ho, a.Wo, a.lnsum != nullptr);
+    ConvGeom gm{KS, STRIDE, MT, NT, CK, false, SPLITK, EPI};
+    const long tile = conv_tile_elems(gm, a.Win, a.Ho, a.Wo, a.row_tiles);
+    const size_t lds = conv_lds_bytes(gm, tile, a.lnsum != nullptr);
     if (lds > 160 * 1024)
         return fail(BDE_ERR_UNSUPPORTED, "conv tile needs %zu B of LDS (> 160 KiB): Win=%d KS=%d CK=%d", lds,
                     a.Win, KS, CK);
-    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, CK, UP2, SPLITK, EPI>;
+    if (conv_stage_items(gm, tile) > MAXI)
+        return fail(BDE_ERR_UNSUPPORTED, "conv tile of %ld elements needs %d staging slots (> %d): Win=%d KS=%d",
+                    tile, conv_stage_items(gm, tile), MAXI, a.Win, KS);
+    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, CK, SPLITK, EPI, MAXI>;
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -420,11 +454,56 @@ static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
     constexpr int BN = (SPLITK ? 1 : 4) * NT * 32;
     const int co_rows = (EPI == EPI_LSTM) ? a.Cout / 4 : a.Cout;          // LSTM: 32 hidden ch per block
     const int co_per_block = (EPI == EPI_LSTM) ? 32 : MT * 32;
-    dim3 grid(cdiv(a.Ho * a.Wo, BN), cdiv(co_rows, co_per_block), G * a.N);
+    dim3 grid(a.row_tiles > 0 ? a.Ho * a.row_tiles : cdiv(a.Ho * a.Wo, BN), cdiv(co_rows, co_per_block), G * a.N);
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
+}
+
+constexpr int CONV_MAXI = 5;   // staging register slots per thread (x CK channels)
+
+template <int KS, int STRIDE>
+static int conv_launch_ks(ConvArgs a, int G, hipStream_t stream) {
+    // choose (NT, tiling mode): most useful pixels per launched pixel among the shapes whose halo
+    // tile fits the staging registers; NT = 2 reuses each weight fragment twice.
+    const int MT = a.Cout > 32 ? 2 : 1;
+    double best = -1.0;
+    int bnt = 1, brow = 0;
+    for (int nt = 2; nt >= 1; --nt)
+        for (int row = 1; row >= 0; --row) {
+            ConvGeom gm{KS, STRIDE, MT, nt, 8, false, false, EPI_GENERIC};
+            const int BN = 4 * nt * 32;
+            const int rt = row ? cdiv(a.Wo, BN) : 0;
+            const long tile = conv_tile_elems(gm, a.Win, a.Ho, a.Wo, rt);
+            if (conv_stage_items(gm, tile) > CONV_MAXI || conv_lds_bytes(gm, tile, false) > 64 * 1024) continue;
+            const double launched = row ? (double)a.Ho * rt * BN : (double)cdiv(a.Ho * a.Wo, BN) * BN;
+            double score = (double)a.Ho * a.Wo / launched * (nt == 2 ? 1.0 : 0.92);
+            const long blocks = (long)(launched / BN) * cdiv(a.Cout, MT * 32) * G * a.N;
+            if (blocks < 512) score *= 0.5 + 0.5 * blocks / 512.0;      // keep 256 CUs busy
+            if (score > best) { best = score; bnt = nt; brow = rt; }
+        }
+    if (best < 0) return fail(BDE_ERR_UNSUPPORTED, "no conv tiling fits: KS=%d stride=%d Win=%d Wo=%d", KS, STRIDE, a.Win, a.Wo);
+    a.row_tiles = brow;
+    if (MT == 2) {
+        if (bnt == 2) return conv_launch_t<KS, STRIDE, 2, 2, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+        return conv_launch_t<KS, STRIDE, 2, 1, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+    }
+    if (bnt == 2) return conv_launch_t<KS, STRIDE, 1, 2, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+    return conv_launch_t<KS, STRIDE, 1, 1, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+}
+
+static int conv_launch_auto(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream) {
+    if (KS == 5 && stride == 1) return conv_launch_ks<5, 1>(a, G, stream);
+    if (KS == 5 && stride == 2) return conv_launch_ks<5, 2>(a, G, stream);
+    if (KS == 3 && stride == 1) return conv_launch_ks<3, 1>(a, G, stream);
+    if (KS == 3 && stride == 2) return conv_launch_ks<3, 2>(a, G, stream);
+    return fail(BDE_ERR_UNSUPPORTED, "conv KS=%d stride=%d not built", KS, stride);
+}
+
+static int lstm_launch(ConvArgs a, hipStream_t stream) {
+    a.row_tiles = cdiv(a.Wo, 32);
+    return conv_launch_t<3, 1, 4, 1, 16, true, EPI_LSTM, 4>(a, 2, stream);
 }
 
 }  // namespace bde

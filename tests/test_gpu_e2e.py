@@ -77,8 +77,10 @@ def test_chunk_independence_property():
     ya = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in a]))
     yb = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in b]))
     yab = torch.stack(m([{'events': torch.from_numpy(np.concatenate([x, y])).cuda()} for x, y in zip(a, b)]))
-    assert maxabs(yab[:, 0:1], ya) <= 1e-6
-    assert maxabs(yab[:, 1:2], yb) <= 1e-6
+    # not bit-exact: the GEMM decomposition (split-K factor) is chosen from the launch size, so the
+    # fp32 summation order differs between B=1 and B=2
+    assert maxabs(yab[:, 0:1], ya) <= 2e-5
+    assert maxabs(yab[:, 1:2], yb) <= 2e-5
 
 
 def test_bad_shapes_raise():
