@@ -87,7 +87,8 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
                 vl[lane * HS + c] = vreg[c];
             }
         }
-        // query of this lane (already scaled by head_dim^-0.5 through the packed weights)
+        // query of this lane; the packed q weights carry head_dim^-0.5 * log2(e) and the bias table
+        // log2(e), so the softmax runs on v_exp_f32 (2^x) directly
         float q[HD];
         {
             const float* qb = a.q + b * a.q_bs + (long)c0 * HW + pixoff;
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
 #pragma unroll
             for (int u = 1; u < 7; ++u) mb = fmaxf(mb, s[u]);
             const float mnew = fmaxf(mx, mb);
-            const float corr = expf(mx - mnew);
+            const float corr = __builtin_amdgcn_exp2f(mx - mnew);
             l *= corr;
 #pragma unroll
             for (int c = 0; c < HD; ++c) o[c] *= corr;
 #pragma unroll
             for (int u = 0; u < 7; ++u) {
-                const float p = expf(s[u] - mnew);
+                const float p = __builtin_amdgcn_exp2f(s[u] - mnew);
                 l += p;
                 const float* vr = vl + (j0 + u) * HS;
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
         for (int c = 0; c < HD; ++c) O[c] = 0.f;
         for (int dd = 0; dd < a.D; ++dd) {
             const float* pp = p0 + (size_t)dd * PS * 64;
-            const float w = expf(pp[0] - M);
+            const float w = __builtin_amdgcn_exp2f(pp[0] - M);
             L += pp[64] * w;
 #pragma unroll
             for (int c = 0; c < HD; ++c) O[c] += pp[(2 + c) * 64] * w;

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "pw_gemm.h"
+#include "token_fused.h"
 #include "voxel.h"
 
 namespace bde {
@@ -167,6 +168,21 @@ static void pack_rows(const DenseLayer& d, const std::vector<int>& rowmap, int C
 }
 
 // Append G dense layers (same shape) to the arena as one grouped packed layer.
+// Fragment order of v_mfma_f32_16x16x4_f32 for the fused token kernel (token_fused.h):
+// [co16 tile][k/4][64 lanes], lane l = W[tile*16 + (l&15)][k4*4 + (l>>4)]; rows and K zero-padded.
+static long pack16(Arena& ar, const float* w, int rows, int K) {
+    const int nct = cdiv(rows, 16), nk4 = cdiv(K, 4);
+    const long off = ar.alloc((long)nct * nk4 * 64);
+    float* dst = ar.host.data() + off;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int k4 = 0; k4 < nk4; ++k4)
+            for (int l = 0; l < 64; ++l) {
+                const int r = ct * 16 + (l & 15), k = k4 * 4 + (l >> 4);
+                dst[((long)ct * nk4 + k4) * 64 + l] = (r < rows && k < K) ? w[(long)r * K + k] : 0.f;
+            }
+    return off;
+}
+
 // Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
 // four (one per wave); pointwise layers CK = 16 in groups of eight (any pw_gemm split-K factor).
 static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, bool lstm) {
@@ -177,7 +193,7 @@ static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& g
     pl.KS = d0.KS;
     pl.lstm = lstm;
     pl.G = (int)groups.size();
-    pl.CK = (lstm || d0.KS == 1) ? 16 : 8;
+    pl.CK = (lstm || d0.KS == 1) ? 16 : conv_ck(d0.KS);
     pl.nchunks = cdiv(d0.Cin, pl.CK);
     if (lstm) pl.nchunks = cdiv(pl.nchunks, 4) * 4;
     if (d0.KS == 1) pl.nchunks = cdiv(pl.nchunks, 8) * 8;
@@ -212,6 +228,7 @@ static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& g
 
 struct AttnBlock {
     PackedLayer qkv, proj, fc1, fc2;
+    long proj16 = -1, fc1_16 = -1, fc2_16 = -1, qkv16 = -1;   // 16x16x4 packings for token_fused.h
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
 };
@@ -227,7 +244,7 @@ struct Workspace {
     float* ev = nullptr;
     float* head = nullptr;
     float* out = nullptr;
-    std::vector<float*> xenc, gx, hseq, cst, merged, kvun, kvref, dec;
+    std::vector<float*> xenc, gx, hseq, cst, merged, kvun, kvref, dec, qkv0;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     void release() {
@@ -256,6 +273,7 @@ struct bde_model {
     Workspace ws;
     int device = 0;
     // optional HIP-event timing of tagged launches / stages (bde_profile_*)
+    long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
     std::vector<ProfSpan> prof;
@@ -380,7 +398,9 @@ static int build_packed(bde_model* m) {
         al.C = m->cout(l);
         if (al.depth == 0) continue;
         const int C = al.C, hid = 4 * C, hd = C / heads;
-        const float scale = 1.0f / std::sqrt((float)hd);
+        // softmax(x) = 2^(x*log2e - max): fold log2(e) into the query scale and the bias table (attn.h)
+        const float LOG2E = 1.4426950408889634f;
+        const float scale = LOG2E / std::sqrt((float)hd);
         DenseLayer kvall;
         kvall.rows = al.depth * 2 * C;
         kvall.Cin = C;
@@ -435,7 +455,7 @@ static int build_packed(bde_model* m) {
                 for (int n = 0; n < N; ++n) {
                     int kd = n / 49, kh = (n % 49) / 7, kw = n % 7;
                     int idx = ((c.q_idx - kd + D - 1) * 13 + (qh - kh + 6)) * 13 + (qw - kw + 6);
-                    for (int h = 0; h < heads; ++h) bt[((long)h * N + n) * 49 + mq] = tbl[(long)idx * heads + h];
+                    for (int h = 0; h < heads; ++h) bt[((long)h * N + n) * 49 + mq] = LOG2E * tbl[(long)idx * heads + h];
                 }
             }
             DenseLayer proj;
@@ -455,6 +475,12 @@ static int build_packed(bde_model* m) {
             fc2.w.assign(w2, w2 + (size_t)C * hid);
             fc2.bias.assign(b2b, b2b + C);
             ab.fc2 = pack_layer(ar, {&fc2}, false);
+            if (C % 16 == 0 && token_lds_bytes(C) <= 150 * 1024) {
+                ab.proj16 = pack16(ar, proj.w.data(), C, C);
+                ab.fc1_16 = pack16(ar, fc1.w.data(), hid, C);
+                ab.fc2_16 = pack16(ar, fc2.w.data(), C, hid);
+                ab.qkv16 = pack16(ar, qkv.w.data(), 3 * C, C);
+            }
         }
         al.kvall = pack_layer(ar, {&kvall}, false);
     }
@@ -585,7 +611,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     BDE_TRY(ws_alloc(ws, &ws.head, TB * c.basechannels * H * W));
     BDE_TRY(ws_alloc(ws, &ws.out, TB * H * W));
     ws.xenc.assign(L, nullptr); ws.gx.assign(L, nullptr); ws.hseq.assign(L, nullptr); ws.cst.assign(L, nullptr);
-    ws.merged.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr);
+    ws.merged.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
     long max_attn = 0;
     for (int l = 0; l < L; ++l) {
         const long C = m->cout(l), hw = (long)(H >> (l + 1)) * (W >> (l + 1));
@@ -597,6 +623,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         if (c.depths[l] > 0) {
             BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
             BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
+            BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
             max_attn = std::max(max_attn, (long)B * C * hw);
         }
         const int j = L - 1 - l;   // decoder j writes the map of level (L-1-j)'s input resolution
@@ -700,8 +727,10 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
 //             ignored for slot q_idx
 //   addres  : tensor added to the result (merged[t], V5.py:166) or nullptr
 //   out     : [B][C][HW]
+//   qkv_first: q|k|v of block blk0 for xq if already computed (batched over T), else nullptr
 static int run_attention_frame(bde_model* m, int l, const float* xq, const float* const* kvslot, const float* addres,
-                               float* out, int B, int H, int W, int blk0, int nblk, hipStream_t s) {
+                               float* out, int B, int H, int W, int blk0, int nblk, const float* qkv_first,
+                               hipStream_t s) {
     const bde_config& c = m->cfg;
     Workspace& ws = m->ws;
     const AttnLevel& al = m->attn[l];
@@ -711,19 +740,23 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
     const int pt = ph / 2, plft = pw / 2;
     const int Hp = H + ph, Wp = W + pw;
     const float* x = xq;
+    const bool fused = al.blocks[0].proj16 >= 0 && cdivl(HW, TOK_PT) * B >= m->fused_min_tiles;
+    bool have_qkv = false;                                   // the fused kernel leaves the next block's q|k|v in ws.qkv
     for (int i = blk0; i < blk0 + nblk; ++i) {
         const AttnBlock& ab = al.blocks[i];
         const bool dil = (i % 2) == 1;                       // DTransformer.py:362
         const bool last = (i == blk0 + nblk - 1);
         // q | k | v of the current x
-        BDE_TRY(run_pw(m, &ab.qkv, x, ws.qkv, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+        const float* qkv = ws.qkv;
+        if (i == blk0 && qkv_first) qkv = qkv_first;
+        else if (!have_qkv) BDE_TRY(run_pw(m, &ab.qkv, x, ws.qkv, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
         AttnArgs a;
         memset(&a, 0, sizeof a);
-        a.q = ws.qkv;
+        a.q = qkv;
         a.q_bs = 3 * C * HW;
         for (int d = 0; d < D; ++d) {
             if (d == c.q_idx) {
-                a.kv[d] = ws.qkv + (long)C * HW;
+                a.kv[d] = qkv + (long)C * HW;
                 a.kv_bs[d] = 3 * C * HW;
             } else if (kvslot[d]) {
                 a.kv[d] = kvslot[d] + (long)i * 2 * C * HW;
@@ -740,11 +773,38 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
         a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
         a.pt = pt; a.pl = plft; a.nWw = Wp / 7; a.dilated = dil ? 1 : 0;
         BDE_TRY(attn_launch(a, B, s));
+        float* dst = last ? out : (x == ws.xa ? ws.xb : ws.xa);
+        if (fused) {
+            TokenArgs ta;
+            memset(&ta, 0, sizeof ta);
+            ta.ao = ws.ao;
+            ta.x = x;
+            ta.addres = last ? addres : nullptr;
+            ta.x2 = dst;
+            ta.wproj = m->P(ab.proj16);  ta.bproj = m->P(ab.proj.b_off);
+            ta.wfc1 = m->P(ab.fc1_16);   ta.bfc1 = m->P(ab.fc1.b_off);  ta.sfc1 = m->P(ab.fc1.s_off);
+            ta.wfc2 = m->P(ab.fc2_16);   ta.bfc2 = m->P(ab.fc2.b_off);
+            if (!last) {
+                const AttnBlock& nb = al.blocks[i + 1];
+                ta.qkv = ws.qkv;
+                ta.wqkv = m->P(nb.qkv16);  ta.bqkv = m->P(nb.qkv.b_off);  ta.sqkv = m->P(nb.qkv.s_off);
+            }
+            ta.bs_c = (long)C * HW;
+            ta.bs_qkv = 3L * C * HW;
+            ta.C = C;
+            ta.HW = (int)HW;
+            ta.mask_w = dil ? W : 0;
+            ta.mask_pt = pt;
+            ta.mask_pl = plft;
+            BDE_TRY(token_launch(ta, B, s));
+            have_qkv = !last;
+            x = dst;
+            continue;
+        }
         // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only)
         BDE_TRY(run_pw(m, &ab.proj, ws.ao, ws.x1, B, HW, ACT_NONE, x, nullptr, dil ? W : 0, pt, plft, s));
         // x2 = x1 + fc2(GELU(fc1(LN(x1))))  (+ merged[t] after the last block)
         BDE_TRY(run_pw(m, &ab.fc1, ws.x1, ws.hid, B, HW, ACT_GELU, nullptr, nullptr, 0, 0, 0, s));
-        float* dst = last ? out : (x == ws.xa ? ws.xb : ws.xa);
         BDE_TRY(run_pw(m, &ab.fc2, ws.hid, dst, B, HW, ACT_NONE, ws.x1, last ? addres : nullptr, 0, 0, 0, s));
         x = dst;
     }
@@ -766,6 +826,8 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
     // K|V of every block for the still-unrefined frames, all T at once
     if (need_un)
         BDE_TRY(run_pw(m, &al.kvall, ws.merged[l], ws.kvun[l], T * B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+    // q|k|v of the first block for every frame at once: its input is the still-unrefined merged[t]
+    BDE_TRY(run_pw(m, &al.blocks[0].qkv, ws.merged[l], ws.qkv0[l], T * B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
     for (int t = 0; t < T; ++t) {
         const float* kvslot[BDE_MAX_FRAMES];
         for (int d = 0; d < D; ++d) {
@@ -775,7 +837,7 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
             else kvslot[d] = ws.kvun[l] + (long)f * kvfs;
         }
         float* mt = ws.merged[l] + (long)t * fs;
-        BDE_TRY(run_attention_frame(m, l, mt, kvslot, mt, mt, B, H, W, 0, al.depth, s));
+        BDE_TRY(run_attention_frame(m, l, mt, kvslot, mt, mt, B, H, W, 0, al.depth, ws.qkv0[l] + (long)t * B * 3 * C * HW, s));
         if (need_ref && t + 1 < T)
             BDE_TRY(run_pw(m, &al.kvall, mt, ws.kvref[l] + (long)t * kvfs, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
     }
@@ -999,6 +1061,12 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
     return forward_impl(m, events, T, B, Hp, Wp, images, (hipStream_t)stream);
 }
 
+int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
+    BDE_REQUIRE(m && key, "null argument");
+    if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
+    return fail(BDE_ERR_ARG, "unknown tuning key '%s'", key);
+}
+
 int bde_profile_reset(bde_model* m, int32_t enable) {
     BDE_REQUIRE(m != nullptr, "null model");
     for (auto& sp : m->prof) { m->prof_pool.push_back(sp.a); m->prof_pool.push_back(sp.b); }
@@ -1154,7 +1222,7 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
         BDE_TRY(run_pw(m, &al.kvall, bufs[d], dst, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
         kvslot[d] = dst;
     }
-    return run_attention_frame(m, level, bufs[c.q_idx], kvslot, nullptr, out, B, H, W, first_block, nblocks, s);
+    return run_attention_frame(m, level, bufs[c.q_idx], kvslot, nullptr, out, B, H, W, first_block, nblocks, nullptr, s);
 }
 
 #pragma GCC visibility pop

@@ -118,7 +118,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
 }
 
 template <int KS, int STRIDE, int MT, int NT, int CK, bool SPLITK, int EPI, int MAXI>
-__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int TAPS = KS * KS;
     constexpr int PAIRS = CK / 2;
@@ -127,7 +127,14 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int STAGE_C = SPLITK ? 4 * CK : CK;   // channels staged per barrier pair
     constexpr int CG = SPLITK ? 8 : 1;        // channel groups of the staging work items
     constexpr int CPI = STAGE_C / CG;         // channels per work item
-    extern __shared__ __align__(16) float lds[];
+    // Without split-K the four waves of a block share the weight fragments of a stage: they are
+    // staged through LDS as well (A region in front of the B halo tile), 4x less L2->L1 traffic
+    // and no global load inside the MFMA loop.
+    constexpr bool ALDS = !SPLITK;
+    constexpr int FRAG = TAPS * PAIRS * 64;   // floats of one co-tile's fragments for one chunk
+    constexpr int ASZ = ALDS ? MT * FRAG : 0;
+    extern __shared__ __align__(16) float lds_all[];
+    float* const lds = lds_all + ASZ;         // B halo tile (and split-K scratch)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.z;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
     float s1[NT], s2[NT];   // per-pixel sum / sum of squares of the B operand (LayerNorm fold)
 #pragma unroll
     for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.f;
-    const bool want_ln = (a.lnsum != nullptr);
+    constexpr bool want_ln = false;   // LayerNorm-folded layers are pointwise: pw_gemm.h
 
     const bool skip_mac = (EPI == EPI_LSTM) && a.first;
     if (!skip_mac) {
@@ -184,9 +191,12 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
         const int tile_elems = R * IW;
         const int nstages = SPLITK ? a.nchunks / 4 : a.nchunks;
         // ---- staging work items of this thread: (tile element, channel group), fixed for all
-        //      stages.  goff < 0: zero padding; lde < 0: no work item.
-        int goff[MAXI];
+        //      stages.  voff = element offset of the work item inside the stage's first channel
+        //      plane (so every load is uniform base + 32-bit lane offset); vmask bit it = the
+        //      element lies inside the image (otherwise zero padding).
+        unsigned voff[MAXI];
         int lde[MAXI], cgi[MAXI];
+        unsigned vmask = 0;
         {
             const float inv_iw = 1.0f / (float)IW;
             const float inv_te = 1.0f / (float)tile_elems;
@@ -200,28 +210,53 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
                 const int iy = iy0 + r, ix = ix0 + col;
                 const bool in_img = (iy >= 0) && (iy < a.Hin) && (ix >= 0) && (ix < a.Win);
                 const bool item = wi < tile_elems * CG;
-                lde[it] = item ? e : -1;
+                lde[it] = item ? e + cg * PS : -1;
                 cgi[it] = cg;
-                goff[it] = (item && in_img) ? iy * a.Ws + ix : -1;
+                if (item && in_img) {
+                    vmask |= 1u << it;
+                    voff[it] = (unsigned)(cg * (int)HsWs + iy * a.Ws + ix);
+                } else {
+                    voff[it] = 0;
+                }
             }
         }
+        constexpr int AKR = ALDS ? (FRAG + 255) / 256 : 0;   // loads per thread and co-tile
         float sv[MAXI][CPI];
+        float aw[ALDS ? MT * AKR : 1];
         auto stage_load = [&](int st) {
             const int c0 = st * STAGE_C;
+            if constexpr (ALDS) {
 #pragma unroll
-            for (int it = 0; it < MAXI; ++it)
+                for (int m = 0; m < MT; ++m) {
+                    const float* wb = wg + (((long)(blockIdx.y * MT + m) * a.nchunks + st) * FRAG);   // uniform
 #pragma unroll
-                for (int j = 0; j < CPI; ++j) {
-                    const int c = c0 + cgi[it] + j * CG;
-                    sv[it][j] = (goff[it] >= 0 && c < a.Cin) ? inb[(long)c * HsWs + goff[it]] : 0.f;
+                    for (int k = 0; k < AKR; ++k)
+                        aw[m * AKR + k] = (tid + k * 256 < FRAG) ? wb[tid + k * 256] : 0.f;
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < CPI; ++j) {
+                const float* cb = inb + (long)(c0 + j * CG) * HsWs;                                  // uniform
+#pragma unroll
+                for (int it = 0; it < MAXI; ++it) {
+                    const bool ok = ((vmask >> it) & 1u) && (c0 + j * CG + cgi[it] < a.Cin);
+                    sv[it][j] = ok ? cb[voff[it]] : 0.f;
+                }
+            }
         };
         auto stage_store = [&]() {
+            if constexpr (ALDS) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int k = 0; k < AKR; ++k)
+                        if (tid + k * 256 < FRAG) lds_all[m * FRAG + tid + k * 256] = aw[m * AKR + k];
+            }
 #pragma unroll
             for (int it = 0; it < MAXI; ++it)
                 if (lde[it] >= 0) {
 #pragma unroll
-                    for (int j = 0; j < CPI; ++j) lds[lde[it] + (cgi[it] + j * CG) * PS] = sv[it][j];
+                    for (int j = 0; j < CPI; ++j) lds[lde[it] + j * CG * PS] = sv[it][j];
                 }
         };
         // software pipeline (register staged, cdna_hip_programming.md T14): the global loads of
@@ -239,17 +274,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 wch[m] = wg + (((long)(blockIdx.y * MT + m) * a.nchunks + chunk) * TAPS * PAIRS) * 64 + lane;
-            if (want_ln) {   // only used with KS == 1
-#pragma unroll
-                for (int pr = 0; pr < PAIRS; ++pr)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        float b = ldsw[boff[t] + pr * 2 * PS];
-                        s1[t] += b;
-                        s2[t] += b * b;
-                    }
-            }
-#pragma unroll
+#pragma unroll 1
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
@@ -258,7 +283,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs a) {
                     for (int pr = 0; pr < PAIRS; ++pr) {
                         float av[MT], bv[NT];
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) av[m] = wch[m][(tap * PAIRS + pr) * 64];
+                        for (int m = 0; m < MT; ++m)
+                            av[m] = ALDS ? lds_all[(m * TAPS * PAIRS + tap * PAIRS + pr) * 64 + lane]
+                                         : wch[m][(tap * PAIRS + pr) * 64];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) bv[t] = ldsw[boff[t] + pr * 2 * PS + ky * IW + kx];
 #pragma unroll
@@ -422,6 +449,7 @@ static inline long conv_tile_elems(const ConvGeom& gm, int Win, int Ho, int Wo, 
 
 static inline size_t conv_lds_bytes(const ConvGeom& gm, long tile_elems, bool ln) {
     long stage = (long)(gm.splitk ? 4 * gm.CK : gm.CK) * tile_elems;
+    if (!gm.splitk) stage += (long)gm.MT * gm.KS * gm.KS * (gm.CK / 2) * 64;   // weight fragments of the stage
     long red = gm.splitk ? (long)gm.MT * gm.NT * 1024 + (ln ? 4 * gm.NT * 128 : 0) : 0;
     long fl = stage > red ? stage : red;
     return (size_t)fl * sizeof(float);
@@ -462,17 +490,20 @@ static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 }
 
 constexpr int CONV_MAXI = 5;   // staging register slots per thread (x CK channels)
+// channels per stage of the generic convs: 5x5 has 25 taps per channel, so half the channels of 3x3
+constexpr int conv_ck(int KS) { return KS >= 5 ? 4 : 8; }
 
 template <int KS, int STRIDE>
 static int conv_launch_ks(ConvArgs a, int G, hipStream_t stream) {
     // choose (NT, tiling mode): most useful pixels per launched pixel among the shapes whose halo
     // tile fits the staging registers; NT = 2 reuses each weight fragment twice.
+    constexpr int CK = conv_ck(KS);
     const int MT = a.Cout > 32 ? 2 : 1;
     double best = -1.0;
     int bnt = 1, brow = 0;
     for (int nt = 2; nt >= 1; --nt)
         for (int row = 1; row >= 0; --row) {
-            ConvGeom gm{KS, STRIDE, MT, nt, 8, false, false, EPI_GENERIC};
+            ConvGeom gm{KS, STRIDE, MT, nt, CK, false, false, EPI_GENERIC};
             const int BN = 4 * nt * 32;
             const int rt = row ? cdiv(a.Wo, BN) : 0;
             const long tile = conv_tile_elems(gm, a.Win, a.Ho, a.Wo, rt);
@@ -486,11 +517,11 @@ static int conv_launch_ks(ConvArgs a, int G, hipStream_t stream) {
     if (best < 0) return fail(BDE_ERR_UNSUPPORTED, "no conv tiling fits: KS=%d stride=%d Win=%d Wo=%d", KS, STRIDE, a.Win, a.Wo);
     a.row_tiles = brow;
     if (MT == 2) {
-        if (bnt == 2) return conv_launch_t<KS, STRIDE, 2, 2, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
-        return conv_launch_t<KS, STRIDE, 2, 1, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+        if (bnt == 2) return conv_launch_t<KS, STRIDE, 2, 2, CK, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+        return conv_launch_t<KS, STRIDE, 2, 1, CK, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
     }
-    if (bnt == 2) return conv_launch_t<KS, STRIDE, 1, 2, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
-    return conv_launch_t<KS, STRIDE, 1, 1, 8, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+    if (bnt == 2) return conv_launch_t<KS, STRIDE, 1, 2, CK, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
+    return conv_launch_t<KS, STRIDE, 1, 1, CK, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
 }
 
 static int conv_launch_auto(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream) {

@@ -154,6 +154,10 @@ class BDE2VID:
                                               C.c_void_p(_stream_ptr(dev))))
         return [out[t] for t in range(T)]
 
+    def set_tuning(self, key: str, value: int):
+        _lib.check(_lib.lib().bde_set_tuning(self._h, key.encode(), int(value)))
+        return self
+
     def get_intermediate(self, name: str, shape) -> torch.Tensor:
         t = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().bde_get_intermediate(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel(),

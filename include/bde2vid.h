@@ -91,6 +91,11 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
  * (level output after attention), "dec<j>".  Layout [T][B][C][H][W]. */
 int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream);
 
+/* Scheduling knobs (results are unchanged up to fp32 summation order).  Keys:
+ *   "fused_min_tiles": a level with at least this many 32-pixel tiles runs the post-softmax part of an
+ *                      attention block as one fused kernel instead of three GEMM launches (default 160). */
+int bde_set_tuning(bde_model* m, const char* key, int64_t value);
+
 /* HIP-event timing of the tagged launches of subsequent bde_forward calls (bench.py's roofline):
  * names "forward", "head", "enc_conv", "gates_x", "lstm<l>" (one span per recurrent step launch),
  * "attn<l>", "decoder".  bde_profile_get synchronises on the recorded events. */

@@ -108,6 +108,24 @@ def test_dframe_attention_level0(blocks):
     assert maxabs(ops.dframe_attention(m, 0, buf), z['attn_l0']) <= TOL
 
 
+@pytest.mark.parametrize('level,shape,seed,key', [(0, (1, 32, 17, 23), 50, 'attn_l0'), (2, (2, 128, 7, 9), 60, 'attn_l2')])
+def test_dframe_attention_fused_token_kernel(blocks, level, shape, seed, key):
+    """Same goldens through the fused proj+MLP+next-qkv kernel (token_fused.h), forced on."""
+    from bde2vid_amd import ops
+    z, cfg, sd, m = blocks
+    buf = [dev(dense_like(shape, seed + d)) for d in range(3)]
+    m.set_tuning('fused_min_tiles', 1)
+    try:
+        y = ops.dframe_attention(m, level, buf)
+        if level == 0:
+            y1 = ops.dframe_attention(m, 0, buf, 1, 1)
+    finally:
+        m.set_tuning('fused_min_tiles', 160)
+    assert maxabs(y, z[key]) <= TOL
+    if level == 0:
+        assert maxabs(y1, z['swin_dilated']) <= TOL
+
+
 def test_dframe_attention_level2_batch2(blocks):
     from bde2vid_amd import ops
     z, cfg, sd, m = blocks

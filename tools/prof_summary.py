@@ -7,10 +7,10 @@ import sys
 
 
 def short(name):
-    m = re.search(r'conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+), (\d)>', name)
+    m = re.search(r'conv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\d+), (\d+)>', name)
     if m:
-        ks, st, mt, nt, ck, up, sk, epi = m.groups()
-        return f'conv_mfma<K{ks} S{st} M{mt} N{nt} CK{ck}{" up2" if up == "true" else ""}{" splitK" if sk == "true" else ""}{" LSTM" if epi == "1" else ""}>'
+        ks, st, mt, nt, ck, sk, epi, maxi = m.groups()
+        return f'conv_mfma<K{ks} S{st} M{mt} N{nt} CK{ck}{" splitK" if sk == "true" else ""}{" LSTM" if epi == "1" else ""}>'
     m = re.search(r'pw_gemm_kernel<(\d+), (\d+), (\w+)>', name)
     if m:
         return f'pw_gemm<M{m.group(1)} N{m.group(2)}{" splitK" if m.group(3) == "true" else ""}>'
