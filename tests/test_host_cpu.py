@@ -1,0 +1,141 @@
+"""CPU-only checks of the host side: C-ABI surface, config/state-dict logic, pad/crop glue,
+multi-process sharding + weight broadcast over gloo (world size 2)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import REPO, GOLDEN
+from bde2vid_amd.config import GeneratorConfig, canonical
+from bde2vid_amd.weights import (state_dict_spec, formula_state_dict, infer_config, num_parameters,
+                                 relative_position_index)
+from bde2vid_amd.harness import Croper, chunked
+
+
+def test_library_exports_every_declared_symbol():
+    """include/bde2vid.h <-> libbde2vid.so <-> ctypes table must agree (no compute call: no GPU here)."""
+    from bde2vid_amd import _lib
+    hdr = open(os.path.join(REPO, 'include', 'bde2vid.h')).read()
+    declared = set(re.findall(r'\b(bde_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.bde_abi_version() == 1
+
+
+def test_create_rejects_bad_config_and_reports_error():
+    import ctypes as C
+    from bde2vid_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.make_config(GeneratorConfig(basechannels=8, depths=(2, 0, 2), num_heads=4))
+    cfg.ks = 7
+    h = C.c_void_p()
+    assert L.bde_create(C.byref(cfg), C.byref(h)) == -1
+    assert b'ks=7' in L.bde_last_error()
+    cfg.ks = 5
+    cfg.buffer_index[1] = 1           # query slot must be offset 0
+    assert L.bde_create(C.byref(cfg), C.byref(h)) == -1
+    cfg.buffer_index[1] = 0
+    assert L.bde_create(C.byref(cfg), C.byref(h)) == 0
+    # loading a weight with a shape the config contradicts is caught at finalize time, before any HIP call
+    w = np.zeros((8, 5, 3, 3), np.float32)
+    sh = (C.c_int64 * 4)(*w.shape)
+    assert L.bde_load_weight(h, b'generator.head.conv2d.weight', w.ctypes.data_as(C.c_void_p), sh, 4) == 0
+    L.bde_destroy(h)
+
+
+def test_product_has_no_cpu_fallback():
+    from bde2vid_amd.model import BDE2VID
+    m = BDE2VID(generator=GeneratorConfig(basechannels=8, depths=(2, 0, 2), num_heads=4))
+    with pytest.raises(RuntimeError):
+        m.to('cpu')
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m.load_state_dict(formula_state_dict(m.cfg))
+    for f in os.listdir(os.path.join(REPO, 'bde2vid_amd')):
+        if f.endswith('.py'):
+            src = open(os.path.join(REPO, 'bde2vid_amd', f)).read()
+            assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_state_dict_spec_and_param_count():
+    assert num_parameters(canonical()) == 20870433          # SURVEY.md §0, measured on the reference
+    cfg = GeneratorConfig(basechannels=16, depths=(1, 2, 3), num_heads=8, buffer_index=(-2, -1, 0, 1, 2), q_idx=2)
+    sd = formula_state_dict(cfg)
+    got = infer_config(sd)
+    assert (got.basechannels, got.depths, got.num_heads, got.buffer_index, got.q_idx, got.ks) == \
+        (16, (1, 2, 3), 8, (-2, -1, 0, 1, 2), 2, 5)
+    a = formula_state_dict(cfg, 7)
+    b = formula_state_dict(cfg, 7)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_unsupported_configs_raise():
+    for kw in (dict(norm='BN'), dict(recurrent_block_type='convgru'), dict(skip_type='concat'),
+               dict(depths=(4, 0, 0)), dict(nwindow_size=(3, 3)), dict(window_size=(8, 8))):
+        with pytest.raises(ValueError):
+            GeneratorConfig(**kw).validate()
+
+
+def test_relative_position_index_shape_and_range():
+    idx = relative_position_index(3, 7, 7)
+    assert idx.shape == (147, 147) and idx.min() == 0 and idx.max() == 5 * 13 * 13 - 1
+    assert idx[0, 0] == idx[100, 100]                        # zero offset -> same table row
+
+
+def test_croper_matches_reference_fixture():
+    ref = json.load(open(os.path.join(GOLDEN, 'croper.json')))
+    for key, r in ref.items():
+        h, w = map(int, key.split('x'))
+        c = Croper(3)
+        c.update_params(w, h)
+        x = torch.arange(h * w, dtype=torch.float32).reshape(1, 1, h, w)
+        p = c.pad(x)
+        assert list(p.shape[-2:]) == r['padded_shape']
+        assert [c.padding_left, c.padding_right, c.padding_top, c.padding_bottom] == r['pad']
+        assert [c.iy0, c.iy1, c.ix0, c.ix1] == r['crop']
+        assert torch.equal(c.crop(p), x)
+
+
+def test_chunked():
+    assert [list(c) for c in chunked(list(range(5)), 2)] == [[0, 1], [2, 3], [4]]
+    assert [list(c) for c in chunked(list(range(3)), None)] == [[0, 1, 2]]
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from bde2vid_amd.dist import init_from_env, shard_sequences, broadcast_packed, max_over_ranks, barrier
+rank, world, local = init_from_env('gloo')
+assert world == 2
+mine = shard_sequences(7, rank, world)
+flat = torch.arange(1000, dtype=torch.float32) if rank == 0 else torch.zeros(1000)
+broadcast_packed(flat, 0)
+assert torch.equal(flat, torch.arange(1000, dtype=torch.float32))
+all_ = [None, None]
+dist.all_gather_object(all_, mine)
+assert sorted(all_[0] + all_[1]) == list(range(7)) and not set(all_[0]) & set(all_[1])
+m = max_over_ranks(1.0 + rank)
+assert m == 2.0
+barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok', mine)
+'''
+
+
+def test_two_rank_gloo_sharding_and_weight_broadcast(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % REPO)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout
