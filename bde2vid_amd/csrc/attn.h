@@ -69,6 +69,12 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
     for (int c = 0; c < HD; ++c) o[c] = 0.f;
 
     if (active) {
+        // bias of the next seven keys is always loaded one batch ahead; the first batch goes out
+        // together with the K/V/q loads
+        const float* bias = a.biasT + ((long)head * a.D + d) * ATT_TOK * ATT_TOK + tok;
+        float sn[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) sn[u] = bias[(long)u * ATT_TOK];
         // ---- stage this slot's 49 keys / values (lane = key token) -------------------------------
         if (lane < ATT_TOK) {
             const float* kp = a.kv[d];
@@ -98,12 +104,15 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes land before its own reads
         __builtin_amdgcn_wave_barrier();
 
-        const float* bias = a.biasT + ((long)head * a.D + d) * ATT_TOK * ATT_TOK + tok;
 #pragma unroll 1
         for (int j0 = 0; j0 < ATT_TOK; j0 += 7) {
             float s[7];
 #pragma unroll
-            for (int u = 0; u < 7; ++u) s[u] = bias[(long)(j0 + u) * ATT_TOK];
+            for (int u = 0; u < 7; ++u) s[u] = sn[u];
+            if (j0 + 7 < ATT_TOK) {
+#pragma unroll
+                for (int u = 0; u < 7; ++u) sn[u] = bias[(long)(j0 + 7 + u) * ATT_TOK];
+            }
 #pragma unroll
             for (int u = 0; u < 7; ++u) {
                 const float* kr = kl + (j0 + u) * HS;

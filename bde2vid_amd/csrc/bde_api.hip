@@ -20,6 +20,7 @@
 #include "conv_mfma.h"
 #include "pw_gemm.h"
 #include "token_fused.h"
+#include "lstm16.h"
 #include "voxel.h"
 
 namespace bde {
@@ -183,6 +184,41 @@ static long pack16(Arena& ar, const float* w, int rows, int K) {
     return off;
 }
 
+// Weight fragments of the recurrent step kernel (lstm16.h):
+// [hidden16 block][chunk of 8 channels][tap][k4][gate][64], lane l = W[gate*Ch + hb*16 + (l&15)][chunk*8 + k4*4 + (l>>4)][tap].
+static PackedLayer pack_lstm16(Arena& ar, const std::vector<const DenseLayer*>& groups) {
+    const DenseLayer& d0 = *groups[0];
+    PackedLayer pl;
+    pl.Cin = d0.Cin;
+    pl.Cout = d0.rows;
+    pl.KS = 3;
+    pl.lstm = true;
+    pl.G = (int)groups.size();
+    pl.CK = L16_CK;
+    pl.nchunks = cdiv(d0.Cin, L16_CK);
+    const int Ch = d0.rows / 4, nhb = cdiv(Ch, 16);
+    pl.ntiles = nhb;
+    pl.w_sz = (long)nhb * pl.nchunks * L16_AFL;
+    pl.w_off = ar.alloc(pl.w_sz * pl.G);
+    pl.b_off = ar.alloc((long)d0.rows * pl.G);
+    for (int g = 0; g < pl.G; ++g) {
+        const DenseLayer& d = *groups[g];
+        float* dst = ar.host.data() + pl.w_off + g * pl.w_sz;
+        for (int hb = 0; hb < nhb; ++hb)
+            for (int ch = 0; ch < pl.nchunks; ++ch)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int k4 = 0; k4 < 2; ++k4)
+                        for (int gate = 0; gate < 4; ++gate)
+                            for (int l = 0; l < 64; ++l) {
+                                const int hc = hb * 16 + (l & 15), ci = ch * 8 + k4 * 4 + (l >> 4);
+                                const long o = ((((long)(hb * pl.nchunks + ch) * 9 + tap) * 2 + k4) * 4 + gate) * 64 + l;
+                                dst[o] = (hc < Ch && ci < d.Cin) ? d.w[((long)(gate * Ch + hc) * d.Cin + ci) * 9 + tap] : 0.f;
+                            }
+        std::copy(d.bias.begin(), d.bias.end(), ar.host.begin() + pl.b_off + (long)g * d0.rows);
+    }
+    return pl;
+}
+
 // Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
 // four (one per wave); pointwise layers CK = 16 in groups of eight (any pw_gemm split-K factor).
 static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, bool lstm) {
@@ -193,7 +229,7 @@ static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& g
     pl.KS = d0.KS;
     pl.lstm = lstm;
     pl.G = (int)groups.size();
-    pl.CK = (lstm || d0.KS == 1) ? 16 : conv_ck(d0.KS);
+    pl.CK = lstm ? LSTM_CK : (d0.KS == 1 ? 16 : conv_ck(d0.KS));
     pl.nchunks = cdiv(d0.Cin, pl.CK);
     if (lstm) pl.nchunks = cdiv(pl.nchunks, 4) * 4;
     if (d0.KS == 1) pl.nchunks = cdiv(pl.nchunks, 8) * 8;
@@ -273,6 +309,13 @@ struct bde_model {
     Workspace ws;
     int device = 0;
     // optional HIP-event timing of tagged launches / stages (bde_profile_*)
+    // side stream: per-frame work that only depends on already-refined frames (next level's encoder /
+    // gate convs, or the decoder) runs beside the sequential attention chain
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> frame_ev;
+    hipEvent_t join_ev = nullptr;
+    int overlap = 0;              // measured neutral-to-negative at config A (contention slows the chain): off
+    int overlap_chunk = 4;        // frames handed to the side stream per launch set
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -388,7 +431,7 @@ static int build_packed(bde_model* m) {
         }
         m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, false);
         m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, false);
-        m->lstm[l] = pack_layer(ar, {&gh[0], &gh[1]}, true);
+        m->lstm[l] = pack_lstm16(ar, {&gh[0], &gh[1]});
     }
     const int D = c.frame_num, heads = c.num_heads;
     const int tbl_rows = (2 * D - 1) * 13 * 13;
@@ -648,16 +691,17 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
 // RecurrentConv sweep of one level for both directions (V5.py:122-135; submodules.py:191-195).
 //   in: [TB][Cin][H][W].  Results: ws.hseq[l] = [2][TB][C][h][w]; ws.cst[l] final cell states.
 // dir_mask: bit0 forward, bit1 backward (the op-level test runs a single direction).
-static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int B, int H, int W, hipStream_t s) {
+// Non-recurrent part of a level for frames [f0, f0+nf) of the [TB] stack: encoder conv (both
+// directions read the same sequence, V5.py:124-130) and the x-part of the gates.
+static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int T, int B, int H, int W, hipStream_t s) {
     Workspace& ws = m->ws;
-    const int C = m->cout(l), h = H / 2, w = W / 2;
+    const int Cin = m->cin(l), C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
-    // encoder conv, both directions read the same sequence (V5.py:124-130)
     ConvCall e;
     e.pl = &m->enc[l];
-    e.in = in;
-    e.out = ws.xenc[l];
-    e.N = (int)TB;
+    e.in = in + (long)f0 * Cin * H * W;
+    e.out = ws.xenc[l] + (long)f0 * C * hw;
+    e.N = nf;
     e.Hs = H;
     e.Ws = W;
     e.stride = 2;
@@ -665,17 +709,26 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     e.in_gs = 0;
     e.out_gs = TB * C * hw;
     { ProfScope ps(m, "enc_conv", s); BDE_TRY(run_conv(m, e, s)); }
-    // x-part of the gates for every t (non-recurrent): gx = conv3x3(x; W[:, :C]) + bias
+    // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
     ConvCall gxc;
     gxc.pl = &m->gx[l];
-    gxc.in = ws.xenc[l];
-    gxc.out = ws.gx[l];
-    gxc.N = (int)TB;
+    gxc.in = ws.xenc[l] + (long)f0 * C * hw;
+    gxc.out = ws.gx[l] + (long)f0 * 4 * C * hw;
+    gxc.N = nf;
     gxc.Hs = h;
     gxc.Ws = w;
     gxc.in_gs = TB * C * hw;
     gxc.out_gs = TB * 4 * C * hw;
     { ProfScope ps(m, "gates_x", s); BDE_TRY(run_conv(m, gxc, s)); }
+    return BDE_OK;
+}
+
+static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int B, int H, int W, hipStream_t s,
+                               bool enc_done = false) {
+    Workspace& ws = m->ws;
+    const int C = m->cout(l), h = H / 2, w = W / 2;
+    const long TB = (long)T * B, hw = (long)h * w;
+    if (!enc_done) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
     // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
     const PackedLayer& pl = m->lstm[l];
     float* hs = ws.hseq[l];
@@ -715,7 +768,7 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         {
             static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
             ProfScope ps(m, names[l], s);
-            BDE_TRY(lstm_launch(a, s));
+            BDE_TRY(lstm16_launch(a, s));
         }
     }
     return BDE_OK;
@@ -811,7 +864,9 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
     return BDE_OK;
 }
 
-static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, hipStream_t s) {
+typedef int (*FrameDoneFn)(bde_model* m, int t, void* ctx);
+static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, hipStream_t s,
+                               FrameDoneFn on_frame = nullptr, void* ctx = nullptr) {
     const bde_config& c = m->cfg;
     Workspace& ws = m->ws;
     const AttnLevel& al = m->attn[l];
@@ -840,6 +895,7 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         BDE_TRY(run_attention_frame(m, l, mt, kvslot, mt, mt, B, H, W, 0, al.depth, ws.qkv0[l] + (long)t * B * 3 * C * HW, s));
         if (need_ref && t + 1 < T)
             BDE_TRY(run_pw(m, &al.kvall, mt, ws.kvref[l] + (long)t * kvfs, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+        if (on_frame) BDE_TRY(on_frame(m, t, ctx));
     }
     return BDE_OK;
 }
@@ -896,35 +952,83 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     hc.Ws = W;
     hc.act = ACT_RELU;
     { ProfScope ps(m, "head", s); BDE_TRY(run_conv(m, hc, s)); }
-    // B. levels (V5.py:119-172)
+    // B. levels (V5.py:119-172).  While the attention chain of a level walks the frames one by one
+    //    (V5.py:154-169), everything that depends only on frames already refined runs on a side
+    //    stream: the next level's encoder + gate convs, or (last level) the decoder.
+    struct SideCtx { int l, T, B, H, W; hipStream_t main, side; bool last; int chunk; };
+    auto decode_frames = [](bde_model* mm, int f0, int nf, int T_, int B_, int H_, int W_, hipStream_t st) -> int {
+        // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x); img = act(predI(x + head))
+        Workspace& w = mm->ws;
+        const int L_ = mm->L;
+        const float* x = w.merged[L_ - 1] + (long)f0 * mm->cout(L_ - 1) * (H_ >> L_) * (W_ >> L_);
+        for (int j = 0; j < L_; ++j) {
+            const int l = L_ - 1 - j;
+            const long in_fs = (long)mm->cout(l) * (H_ >> (l + 1)) * (W_ >> (l + 1));
+            const long out_fs = (long)mm->cin(l) * (H_ >> l) * (W_ >> l);
+            ProfScope ps(mm, "decoder", st);
+            BDE_TRY(run_decoder(mm, j, x, w.merged[l] + (long)f0 * in_fs, w.dec[j] + (long)f0 * out_fs, nf,
+                                H_ >> (l + 1), W_ >> (l + 1), st));
+            x = w.dec[j] + (long)f0 * out_fs;
+        }
+        const long total = (long)nf * H_ * W_;
+        long blocks = std::min<long>(cdivl(total, 256), 4096);
+        hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x,
+                           w.head + (long)f0 * mm->cfg.basechannels * H_ * W_, mm->P(mm->predw_off),
+                           mm->P(mm->predb_off), w.out + (long)f0 * H_ * W_, mm->cfg.basechannels, (long)H_ * W_, total,
+                           mm->cfg.activation);
+        BDE_HIP(hipGetLastError());
+        return BDE_OK;
+    };
+    static auto decode_fn = decode_frames;
+    const bool overlap = m->overlap != 0;
+    if (overlap && !m->side) {
+        int lo = 0, hi = 0;                               // lowest priority: the chain on the main stream goes first
+        BDE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        BDE_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo));
+        BDE_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
+    }
+    while (overlap && (int)m->frame_ev.size() < T) {
+        hipEvent_t e;
+        BDE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->frame_ev.push_back(e);
+    }
     const float* target = ws.head;
+    bool enc_done = false, decoded = false;
     for (int l = 0; l < L; ++l) {
         const int Hl = H >> l, Wl = W >> l, h = Hl / 2, w = Wl / 2, C = m->cout(l);
-        BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s));
+        BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s, enc_done));
+        enc_done = false;
         const long n = TB * C * h * w;
         BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s));   // V5.py:137-147
         if (c.depths[l] > 0) {
             static const char* names[BDE_MAX_LEVELS] = {"attn0", "attn1", "attn2", "attn3", "attn4", "attn5", "attn6", "attn7"};
             ProfScope ps(m, names[l], s);
-            BDE_TRY(run_attention_level(m, l, T, B, h, w, s));
+            SideCtx sc{l, T, B, H, W, s, m->side, l == L - 1, m->overlap_chunk};
+            FrameDoneFn fn = nullptr;
+            if (overlap) {
+                fn = [](bde_model* mm, int t, void* vp) -> int {
+                    SideCtx* q = (SideCtx*)vp;
+                    // hand the refined frames to the side stream in chunks (bigger grids per launch)
+                    const int done = t + 1;
+                    if (done % q->chunk != 0 && done != q->T) return BDE_OK;
+                    const int t0 = (done - 1) / q->chunk * q->chunk, nt = done - t0;
+                    BDE_HIP(hipEventRecord(mm->frame_ev[t], q->main));
+                    BDE_HIP(hipStreamWaitEvent(q->side, mm->frame_ev[t], 0));
+                    if (q->last) return decode_fn(mm, t0 * q->B, nt * q->B, q->T, q->B, q->H, q->W, q->side);
+                    const int ln = q->l + 1;
+                    return run_enc_gx(mm, ln, mm->ws.merged[q->l], t0 * q->B, nt * q->B, q->T, q->B, q->H >> ln, q->W >> ln, q->side);
+                };
+            }
+            BDE_TRY(run_attention_level(m, l, T, B, h, w, s, fn, &sc));
+            if (overlap) {
+                BDE_HIP(hipEventRecord(m->join_ev, m->side));
+                BDE_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+                if (l == L - 1) decoded = true; else enc_done = true;
+            }
         }
         target = ws.merged[l];
     }
-    // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x)
-    const float* x = ws.merged[L - 1];
-    for (int j = 0; j < L; ++j) {
-        const int l = L - 1 - j;
-        { ProfScope ps(m, "decoder", s);
-          BDE_TRY(run_decoder(m, j, x, ws.merged[l], ws.dec[j], (int)TB, H >> (l + 1), W >> (l + 1), s)); }
-        x = ws.dec[j];
-    }
-    {
-        const long total = TB * H * W;
-        long blocks = std::min<long>(cdivl(total, 256), 4096);
-        hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ws.head, m->P(m->predw_off),
-                           m->P(m->predb_off), ws.out, c.basechannels, (long)H * W, total, c.activation);
-        BDE_HIP(hipGetLastError());
-    }
+    if (!decoded) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s));
     for (int t = 0; t < T; ++t)
         BDE_HIP(hipMemcpyAsync(images[t], ws.out + t * img_fs, sizeof(float) * img_fs, hipMemcpyDeviceToDevice, s));
     return BDE_OK;
@@ -979,6 +1083,9 @@ void bde_destroy(bde_model* m) {
     if (m->dev) (void)hipFree(m->dev);
     for (auto& sp : m->prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : m->prof_pool) (void)hipEventDestroy(e);
+    for (auto e : m->frame_ev) (void)hipEventDestroy(e);
+    if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+    if (m->side) (void)hipStreamDestroy(m->side);
     delete m;
 }
 
@@ -1064,7 +1171,22 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
 int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     BDE_REQUIRE(m && key, "null argument");
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
+    if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "overlap") { m->overlap = (int)value; return BDE_OK; }
+    if (std::string(key) == "overlap_chunk") { m->overlap_chunk = std::max<int>(1, (int)value); return BDE_OK; }
     return fail(BDE_ERR_ARG, "unknown tuning key '%s'", key);
+}
+
+int bde_debug_occupancy(const char* kernel) {
+    int nb = -1;
+    std::string k(kernel ? kernel : "");
+    hipError_t e = hipErrorInvalidValue;
+    if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64>, 256, 0);
+    else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32>, 256, 0);
+    else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel, 256, token_lds_bytes(64));
+    else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, CONV_MAXI>, 256, 42 * 1024);
+    if (e != hipSuccess) return -1;
+    return nb;
 }
 
 int bde_profile_reset(bde_model* m, int32_t enable) {

@@ -87,6 +87,16 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
     const float* r1 = a.res1 ? a.res1 + g * a.res1_gs + n * a.res1_ns : nullptr;
     const float* r2 = a.res2 ? a.res2 + g * a.res2_gs + n * a.res2_ns : nullptr;
     const float* biasg = a.bias + g * a.bias_gs;
+    // per-row parameters first (all loads in flight together), then the per-element work
+    float bv[MT][RPW], sv[MT][RPW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int co = min((int)(blockIdx.y * MT + m) * 32 + acc_row(r0 + rr, lane), a.Cout - 1);
+            bv[m][rr] = biasg[co];
+            sv[m][rr] = want_ln ? a.lnsum[co] : 0.f;
+        }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int p = pix[t];
@@ -100,18 +110,24 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int cob = (blockIdx.y * MT + m) * 32;
+            float rv[RPW];
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int co = cob + acc_row(r0 + rr, lane);
+                const long o = (long)min(co, a.Cout - 1) * HW + p;
+                rv[rr] = 0.f;
+                if (r1) rv[rr] = r1[o];
+                if (r2) rv[rr] += r2[o];
+            }
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
                 const int co = cob + acc_row(r0 + rr, lane);
                 if (co >= a.Cout) continue;
                 float v = fin[m][t][rr];
-                if (want_ln) v = rstd[t] * (v - mu[t] * a.lnsum[co]);
-                v = act_apply(v + biasg[co], a.act);
+                if (want_ln) v = rstd[t] * (v - mu[t] * sv[m][rr]);
+                v = act_apply(v + bv[m][rr], a.act);
                 if (!covered) v = 0.f;
-                const long o = (long)co * HW + p;
-                if (r1) v += r1[o];
-                if (r2) v += r2[o];
-                outb[o] = v;
+                outb[(long)co * HW + p] = v + rv[rr];
             }
         }
     }
@@ -492,6 +508,7 @@ static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 constexpr int CONV_MAXI = 5;   // staging register slots per thread (x CK channels)
 // channels per stage of the generic convs: 5x5 has 25 taps per channel, so half the channels of 3x3
 constexpr int conv_ck(int KS) { return KS >= 5 ? 4 : 8; }
+constexpr int LSTM_CK = 16;    // channels per wave and stage of the recurrent step (4 waves -> 32 per stage)
 
 template <int KS, int STRIDE>
 static int conv_launch_ks(ConvArgs a, int G, hipStream_t stream) {
@@ -534,7 +551,7 @@ static int conv_launch_auto(int KS, int stride, const ConvArgs& a, int G, hipStr
 
 static int lstm_launch(ConvArgs a, hipStream_t stream) {
     a.row_tiles = cdiv(a.Wo, 32);
-    return conv_launch_t<3, 1, 4, 1, 16, true, EPI_LSTM, 4>(a, 2, stream);
+    return conv_launch_t<3, 1, 4, 1, LSTM_CK, true, EPI_LSTM, 4>(a, 2, stream);
 }
 
 }  // namespace bde

@@ -55,7 +55,7 @@ __device__ __forceinline__ void pw_mac(const PwFrag<MT, NT, U>& f, f32x16 (&acc)
 template <int MT, int NT, int WS>
 __global__ __launch_bounds__(WS == 1 ? 256 : 64 * WS) void pw_gemm_kernel(const ConvArgs a) {
     constexpr bool SPLIT = WS > 1;
-    constexpr int U = 8;                          // k-pairs per register buffer (two buffers in flight)
+    constexpr int U = (MT * NT <= 2) ? 16 : 8;    // k-pairs per register buffer (two buffers in flight)
     constexpr int WN = SPLIT ? 1 : 4;
     constexpr int BN = WN * NT * 32;
     extern __shared__ __align__(16) float lds[];
@@ -219,17 +219,28 @@ static int pw_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 
 // Pick the decomposition of one pointwise GEMM launch: enough waves to cover the 1024 SIMDs,
 // as little reduction as possible.
+inline int& pw_force_ref() { static int v = 0; return v; }   // debug/tuning: mt*100 + nt*10 + ws, 0 = auto
+
 static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
+    if (const int f = pw_force_ref(); f != 0 && (long)G * a.N <= 4) {
+        switch (f) {
+            case 211: return pw_launch_t<2, 1, 1>(a, G, stream);
+            case 111: return pw_launch_t<1, 1, 1>(a, G, stream);
+            case 114: return pw_launch_t<1, 1, 4>(a, G, stream);
+            case 118: return pw_launch_t<1, 1, 8>(a, G, stream);
+            default: break;
+        }
+    }
     const long px_tiles = cdiv(a.Wo, 32);
     const long frames = (long)G * a.N;
     const int kpairs = a.Cin / 2;
     const long t2 = px_tiles * cdiv(a.Cout, 64) * frames;     // wave tasks with MT = 2
     const long t1 = px_tiles * cdiv(a.Cout, 32) * frames;     // wave tasks with MT = 1
     if (t2 / 2 >= 4096) return pw_launch_t<2, 2, 1>(a, G, stream);   // T-batched: maximise reuse
-    if (t2 >= 768) return pw_launch_t<2, 1, 1>(a, G, stream);
+    if (t2 >= 2048) return pw_launch_t<2, 1, 1>(a, G, stream);
     if (t1 >= 768) return pw_launch_t<1, 1, 1>(a, G, stream);
-    // few tiles: split K over the waves of a block
-    if (t2 * 4 >= 768 && kpairs >= 64) return pw_launch_t<2, 1, 4>(a, G, stream);
+    // few tiles (one frame of a small map): split K over the waves of a block; one 32x32 tile per
+    // wave measured faster than two on the level-2 chain (more blocks, shorter per-wave chains)
     if (kpairs >= 256 && t1 * 4 < 1024) return pw_launch_t<1, 1, 8>(a, G, stream);
     if (kpairs >= 32) return pw_launch_t<1, 1, 4>(a, G, stream);
     return pw_launch_t<1, 1, 1>(a, G, stream);

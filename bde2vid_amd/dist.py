@@ -20,10 +20,11 @@ def init_from_env(backend: str = None):
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('BDE_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    if backend == 'nccl':
+    if torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)   # (functional tests put two ranks on one GPU over gloo)
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

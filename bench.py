@@ -116,7 +116,7 @@ def main():
     log('start')
     rank, world, local = init_from_env()
     assert world == max(args.gpus, 1) or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     cfg = canonical()
     sd_holder = {}
@@ -125,6 +125,10 @@ def main():
         sd_holder['sd'] = formula_state_dict(cfg)
         return sd_holder['sd']
     model = build_replicated_model(cfg, get_sd, device)
+    for kv in os.environ.get('BDE_TUNING', '').split(','):
+        if '=' in kv:
+            k, v = kv.split('=')
+            model.set_tuning(k, int(v))
     log('weights packed and resident')
 
     cp = crop_params(args.width, args.height, cfg.num_encoders)

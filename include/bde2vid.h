@@ -96,6 +96,9 @@ int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t num
  *                      attention block as one fused kernel instead of three GEMM launches (default 160). */
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 
+/* Diagnostics: resident workgroups per CU the runtime reports for a named kernel (-1 = unknown). */
+int bde_debug_occupancy(const char* kernel);
+
 /* HIP-event timing of the tagged launches of subsequent bde_forward calls (bench.py's roofline):
  * names "forward", "head", "enc_conv", "gates_x", "lstm<l>" (one span per recurrent step launch),
  * "attn<l>", "decoder".  bde_profile_get synchronises on the recorded events. */

@@ -12,6 +12,10 @@ stage = sys.argv[1] if len(sys.argv) > 1 else 'lstm0'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 cfg = canonical()
 m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
+if os.environ.get('PW_FORCE'):
+    m.set_tuning('pw_force', int(os.environ['PW_FORCE']))
+if os.environ.get('FUSED_MIN'):
+    m.set_tuning('fused_min_tiles', int(os.environ['FUSED_MIN']))
 H, W, T = 184, 240, 16
 g = torch.Generator(device='cuda').manual_seed(0)
 
