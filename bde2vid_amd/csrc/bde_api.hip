@@ -316,6 +316,8 @@ struct bde_model {
     hipEvent_t join_ev = nullptr;
     int overlap = 0;              // measured neutral-to-negative at config A (contention slows the chain): off
     int overlap_chunk = 4;        // frames handed to the side stream per launch set
+    int tok_debug = 0;
+    unsigned long long* tok_stamps = nullptr;
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -793,7 +795,7 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
     const int pt = ph / 2, plft = pw / 2;
     const int Hp = H + ph, Wp = W + pw;
     const float* x = xq;
-    const bool fused = al.blocks[0].proj16 >= 0 && cdivl(HW, TOK_PT) * B >= m->fused_min_tiles;
+    const bool fused = al.blocks[0].proj16 >= 0 && cdivl(HW, 32) * B >= m->fused_min_tiles;
     bool have_qkv = false;                                   // the fused kernel leaves the next block's q|k|v in ws.qkv
     for (int i = blk0; i < blk0 + nblk; ++i) {
         const AttnBlock& ab = al.blocks[i];
@@ -849,6 +851,8 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
             ta.mask_w = dil ? W : 0;
             ta.mask_pt = pt;
             ta.mask_pl = plft;
+            ta.debug = m->tok_debug;
+            ta.stamps = m->tok_stamps;
             BDE_TRY(token_launch(ta, B, s));
             have_qkv = !last;
             x = dst;
@@ -1172,9 +1176,25 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     BDE_REQUIRE(m && key, "null argument");
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "tok_debug") { m->tok_debug = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap") { m->overlap = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap_chunk") { m->overlap_chunk = std::max<int>(1, (int)value); return BDE_OK; }
     return fail(BDE_ERR_ARG, "unknown tuning key '%s'", key);
+}
+
+int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n) {
+    // diagnostic: enable (host_out == NULL) or read back (n values) the token-kernel phase stamps
+    BDE_REQUIRE(m != nullptr, "null model");
+    if (!m->tok_stamps) {
+        BDE_HIP(hipMalloc((void**)&m->tok_stamps, sizeof(unsigned long long) * 64 * 4 * 8));
+        BDE_HIP(hipMemset(m->tok_stamps, 0, sizeof(unsigned long long) * 64 * 4 * 8));
+    }
+    if (host_out) {
+        BDE_HIP(hipDeviceSynchronize());
+        BDE_HIP(hipMemcpy(host_out, m->tok_stamps, sizeof(int64_t) * std::min(n, 64 * 4 * 8), hipMemcpyDeviceToHost));
+    }
+    return BDE_OK;
 }
 
 int bde_debug_occupancy(const char* kernel) {
@@ -1183,8 +1203,8 @@ int bde_debug_occupancy(const char* kernel) {
     hipError_t e = hipErrorInvalidValue;
     if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64>, 256, 0);
     else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32>, 256, 0);
-    else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel, 256, token_lds_bytes(64));
-    else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, CONV_MAXI>, 256, 42 * 1024);
+    else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64));
+    else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, conv_maxi(3)>, 256, 42 * 1024);
     if (e != hipSuccess) return -1;
     return nb;
 }

@@ -66,10 +66,28 @@ struct ConvArgs {
     int first;           // 1: h_prev == 0 -> skip the contraction entirely
 };
 
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU
+// epilogues sit on the sequential attention chain, where libm's erff (a ~60-instruction branchy
+// routine) cost more than the GEMM it follows.  GELU(x) = 0.5 x (1 + erf(x/sqrt2)) then deviates
+// from nn.GELU() by < 1e-7 |x|, three orders below the parity tolerance.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = 1.0f - p * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752440f)); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == ACT_GELU) return gelu_f(v);
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
@@ -505,7 +523,8 @@ static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
     return BDE_OK;
 }
 
-constexpr int CONV_MAXI = 5;   // staging register slots per thread (x CK channels)
+// staging register slots per thread: 40 prefetched values = slots x CK channels
+constexpr int conv_maxi(int KS) { return KS >= 5 ? 10 : 5; }
 // channels per stage of the generic convs: 5x5 has 25 taps per channel, so half the channels of 3x3
 constexpr int conv_ck(int KS) { return KS >= 5 ? 4 : 8; }
 constexpr int LSTM_CK = 16;    // channels per wave and stage of the recurrent step (4 waves -> 32 per stage)
@@ -515,6 +534,7 @@ static int conv_launch_ks(ConvArgs a, int G, hipStream_t stream) {
     // choose (NT, tiling mode): most useful pixels per launched pixel among the shapes whose halo
     // tile fits the staging registers; NT = 2 reuses each weight fragment twice.
     constexpr int CK = conv_ck(KS);
+    constexpr int CONV_MAXI = conv_maxi(KS);
     const int MT = a.Cout > 32 ? 2 : 1;
     double best = -1.0;
     int bnt = 1, brow = 0;

@@ -98,6 +98,9 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 
 /* Diagnostics: resident workgroups per CU the runtime reports for a named kernel (-1 = unknown). */
 int bde_debug_occupancy(const char* kernel);
+/* Diagnostics: s_memtime stamps of the fused token kernel's phases ([block<64][wave][8]); first call
+ * with host_out == NULL enables them, a later call copies n values back. */
+int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n);
 
 /* HIP-event timing of the tagged launches of subsequent bde_forward calls (bench.py's roofline):
  * names "forward", "head", "enc_conv", "gates_x", "lstm<l>" (one span per recurrent step launch),

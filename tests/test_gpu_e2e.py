@@ -93,3 +93,60 @@ def test_bad_shapes_raise():
         m([{'events': torch.zeros(1, 5, 60, 64, device='cuda')}])
     with pytest.raises(RuntimeError):     # 32x40 -> 4x5 map at level 2 < 7x7 window (reference raises too)
         m([{'events': torch.zeros(1, 5, 32, 40, device='cuda')}])
+
+
+@pytest.mark.parametrize('hw,T,B', [((260, 346), 3, 2), ((480, 640), 2, 1)])
+def test_baseline_resolutions_vs_oracle(hw, T, B):
+    """BASELINE.json configs[2..3] resolutions (DAVIS346 padded to 264x352 through Croper, VGA) with a
+    small-channel model so the CPU oracle finishes in seconds; exercises row-tiled convs, multi-tile
+    rows in the recurrent kernel and non-multiple-of-7 attention maps."""
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.config import GeneratorConfig
+    from bde2vid_amd.weights import formula_state_dict
+    from bde2vid_amd.harness import reconstruct_sequence, Croper
+    from oracle import bde2vid_oracle as O
+    from tests.util import voxel_like
+    cfg = GeneratorConfig(basechannels=8, depths=(1, 0, 2), num_heads=4)
+    sd = formula_state_dict(cfg)
+    m = build_model(cfg, sd, 'cuda:0')
+    vox = [torch.from_numpy(voxel_like((B, 5, hw[0], hw[1]), 1200 + t)) for t in range(T)]
+    got = torch.stack(reconstruct_sequence(m, [v.cuda() for v in vox])).cpu()
+    crop = Croper(3)
+    crop.update_params(hw[1], hw[0])
+    with torch.no_grad():
+        ref = torch.stack([crop.crop(y) for y in O.forward(sd, cfg, [{'events': crop.pad(v)} for v in vox])])
+    assert got.shape == ref.shape == (T, B, 1, hw[0], hw[1])
+    assert maxabs(got, ref) <= TOL
+
+
+def test_hd_frame_runs_and_is_finite():
+    """Largest BASELINE size (720x1280): shape/LDS limits of every kernel, output in (0,1)."""
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.config import GeneratorConfig
+    from bde2vid_amd.weights import formula_state_dict
+    from tests.util import voxel_like
+    cfg = GeneratorConfig(basechannels=8, depths=(1, 0, 1), num_heads=4)
+    m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
+    y = torch.stack(m([{'events': torch.from_numpy(voxel_like((1, 5, 720, 1280), 1300 + t)).cuda()} for t in range(2)]))
+    assert tuple(y.shape) == (2, 1, 1, 720, 1280)
+    assert torch.isfinite(y).all() and float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    assert float(y.std()) > 0.01
+
+
+def test_chunking_changes_only_chunk_edges_like_reference():
+    """subseq_L chunking (eval_models_seq.py:216-219): every chunk starts from zero state, so running
+    two chunks equals two independent forwards (and differs from one long forward)."""
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.config import GeneratorConfig
+    from bde2vid_amd.weights import formula_state_dict
+    from bde2vid_amd.harness import reconstruct_sequence
+    from tests.util import voxel_like
+    cfg = GeneratorConfig(basechannels=8, depths=(2, 0, 2), num_heads=4)
+    m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
+    vox = [torch.from_numpy(voxel_like((1, 5, 56, 64), 1400 + t)).cuda() for t in range(6)]
+    whole = torch.stack(reconstruct_sequence(m, vox, subseq_L=None))
+    chunks = torch.stack(reconstruct_sequence(m, vox, subseq_L=3))
+    a = torch.stack(m([{'events': v} for v in vox[:3]]))
+    b = torch.stack(m([{'events': v} for v in vox[3:]]))
+    assert torch.equal(chunks, torch.cat([a, b]))
+    assert maxabs(whole, chunks) > 1e-3

@@ -14,6 +14,10 @@ cfg = canonical()
 m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
 if os.environ.get('PW_FORCE'):
     m.set_tuning('pw_force', int(os.environ['PW_FORCE']))
+if os.environ.get('TOK_NPT'):
+    m.set_tuning('tok_npt', int(os.environ['TOK_NPT']))
+if os.environ.get('TOK_DEBUG'):
+    m.set_tuning('tok_debug', int(os.environ['TOK_DEBUG']))
 if os.environ.get('FUSED_MIN'):
     m.set_tuning('fused_min_tiles', int(os.environ['FUSED_MIN']))
 H, W, T = 184, 240, 16
