@@ -82,10 +82,14 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
             const float* kb = use ? kp + b * a.kv_bs[d] + (long)c0 * HW + pixoff : nullptr;
             const float* vb = use ? kb + a.v_off[d] : nullptr;
             float kreg[HD], vreg[HD];
+            // pointer select + unconditional load (a load under a per-lane branch costs a vmcnt(0) join)
+            const float* ksrc = use ? kb : a.kvpad + c0;
+            const float* vsrc = use ? vb : a.kvpad + a.C + c0;
+            const long cstride = use ? (long)HW : 1;
 #pragma unroll
             for (int c = 0; c < HD; ++c) {
-                kreg[c] = use ? kb[(long)c * HW] : a.kvpad[c0 + c];
-                vreg[c] = use ? vb[(long)c * HW] : a.kvpad[a.C + c0 + c];
+                kreg[c] = ksrc[c * cstride];
+                vreg[c] = vsrc[c * cstride];
             }
 #pragma unroll
             for (int c = 0; c < HD; ++c) {
@@ -99,7 +103,10 @@ __global__ __launch_bounds__(1024) void attn_core_kernel(const AttnArgs a) {
         {
             const float* qb = a.q + b * a.q_bs + (long)c0 * HW + pixoff;
 #pragma unroll
-            for (int c = 0; c < HD; ++c) q[c] = valid ? qb[(long)c * HW] : 0.f;
+            for (int c = 0; c < HD; ++c) {
+                const float v = qb[(long)c * HW];          // pixoff is 0 for invalid tokens: in bounds
+                q[c] = valid ? v : 0.f;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes land before its own reads
         __builtin_amdgcn_wave_barrier();

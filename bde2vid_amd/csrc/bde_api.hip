@@ -767,6 +767,7 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         a.Ho = h;
         a.Wo = w;
         a.nchunks = pl.nchunks;
+        a.dbg_stamps = (l == 0 && st == T - 1) ? m->tok_stamps : nullptr;   // diagnostics (bde_debug_token_stamps)
         {
             static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
             ProfScope ps(m, names[l], s);

@@ -64,6 +64,7 @@ struct ConvArgs {
     float* cstate;       // [G][N][Ch][HW]    cell state, updated in place
     long gx_gs, gx_ns, c_gs, c_ns;
     int first;           // 1: h_prev == 0 -> skip the contraction entirely
+    unsigned long long* dbg_stamps;   // diagnostics only (lstm16.h): s_memtime per stage phase
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU
@@ -263,22 +264,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const float* wb = wg + (((long)(blockIdx.y * MT + m) * a.nchunks + st) * FRAG);   // uniform
+                    // all staging loads are UNCONDITIONAL (index clamped, value selected afterwards): a
+                    // load under a per-lane condition makes hipcc branch around it and wait vmcnt(0)
+                    // at the join -- one full memory round trip per load
 #pragma unroll
-                    for (int k = 0; k < AKR; ++k)
-                        aw[m * AKR + k] = (tid + k * 256 < FRAG) ? wb[tid + k * 256] : 0.f;
+                    for (int k = 0; k < AKR; ++k) aw[m * AKR + k] = wb[min(tid + k * 256, FRAG - 1)];
                 }
             }
 #pragma unroll
             for (int j = 0; j < CPI; ++j) {
-                const float* cb = inb + (long)(c0 + j * CG) * HsWs;                                  // uniform
+                // channel base clamped so that even padded channels read inside the tensor
+                const int cbase = min(c0 + j * CG, a.Cin - CG);
+                const float* cb = inb + (long)cbase * HsWs;                                         // uniform
 #pragma unroll
-                for (int it = 0; it < MAXI; ++it) {
-                    const bool ok = ((vmask >> it) & 1u) && (c0 + j * CG + cgi[it] < a.Cin);
-                    sv[it][j] = ok ? cb[voff[it]] : 0.f;
-                }
+                for (int it = 0; it < MAXI; ++it) sv[it][j] = cb[voff[it]];   // masked when stored to LDS
             }
         };
-        auto stage_store = [&]() {
+        auto stage_store = [&](int st) {
+            const int c0 = st * STAGE_C;
             if constexpr (ALDS) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -289,8 +292,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < MAXI; ++it)
                 if (lde[it] >= 0) {
+                    const bool in_img = (vmask >> it) & 1u;
 #pragma unroll
-                    for (int j = 0; j < CPI; ++j) lds[lde[it] + j * CG * PS] = sv[it][j];
+                    for (int j = 0; j < CPI; ++j)
+                        lds[lde[it] + j * CG * PS] = (in_img && (c0 + j * CG + cgi[it] < a.Cin)) ? sv[it][j] : 0.f;
                 }
         };
         // software pipeline (register staged, cdna_hip_programming.md T14): the global loads of
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         stage_load(0);
         for (int st = 0; st < nstages; ++st) {
             __syncthreads();   // previous stage fully consumed
-            stage_store();
+            stage_store(st);
             __syncthreads();
             if (st + 1 < nstages) stage_load(st + 1);
             // ---- contraction over this stage's channels ---------------------------------

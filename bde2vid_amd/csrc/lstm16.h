@@ -24,7 +24,7 @@ typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 constexpr int L16_CK = 8;                        // channels per stage
 constexpr int L16_AFL = 9 * 2 * 4 * 64;          // floats of one stage's weight fragments (18 KiB)
-constexpr int L16_AK = L16_AFL / 256;            // 18 loads per thread
+constexpr int L16_AK4 = (L16_AFL / 4 + 255) / 256;  // 16-byte loads per thread (5; 1152 float4 per stage)
 // plane stride of the halo tile, padded to 16 (mod 32) floats
 constexpr int l16_ps(int rows, int pxw) { return ((rows + 2) * (pxw + 2) + 15) / 32 * 32 + 16; }
 
@@ -77,40 +77,69 @@ __global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
             if (ok) bmask |= 1u << k;
             bsrc[k] = ok ? (unsigned)(ci * HW + iy * W + ix) : 0u;
         }
-        float aw[L16_AK], bw[L16_BK];
+        float4 aw[L16_AK4];
+        float bw[L16_BK];
         auto stage_load = [&](int st) {
             const float* wsrc = wg + (long)st * L16_AFL;
+            // 16-byte loads: the vector-memory issue slot, not bandwidth, is what a stage of 25 dword
+            // loads per thread was waiting on (measured: 3-4k cycles just to issue them)
 #pragma unroll
-            for (int k = 0; k < L16_AK; ++k) aw[k] = wsrc[tid + k * 256];
+            for (int k = 0; k < L16_AK4; ++k) {
+                const int i4 = min(tid + k * 256, L16_AFL / 4 - 1);
+                aw[k] = reinterpret_cast<const float4*>(wsrc)[i4];
+            }
             const float* cb = inb + (long)st * L16_CK * HW;
 #pragma unroll
+            // (measured: the L2 round trip under this kernel's load is 4-5k cycles, longer than one
+            //  stage, so a one-stage register prefetch cannot hide it whichever way the zero-padding
+            //  select is placed; this form -- exec-masked loads -- was the fastest of the three tried)
             for (int k = 0; k < L16_BK; ++k) bw[k] = ((bmask >> k) & 1u) ? cb[bsrc[k]] : 0.f;
         };
         const int bofl = (lane >> 4) * L16_PS + wrow * L16_IW + pxl;   // tap (0,0), k4 = 0
         const int nst = a.nchunks;
         stage_load(0);
         for (int st = 0; st < nst; ++st) {
+            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
+                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 0] = __builtin_amdgcn_s_memtime();
             __syncthreads();
+            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
+                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
-            for (int k = 0; k < L16_AK; ++k) ldsA[tid + k * 256] = aw[k];
+            for (int k = 0; k < L16_AK4; ++k) {
+                const int i4 = tid + k * 256;
+                if (i4 < L16_AFL / 4) reinterpret_cast<float4*>(ldsA)[i4] = aw[k];
+            }
 #pragma unroll
             for (int k = 0; k < L16_BK; ++k)
                 if (boffs[k] >= 0) ldsB[boffs[k]] = bw[k];
             __syncthreads();
+            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
+                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 2] = __builtin_amdgcn_s_memtime();
             if (st + 1 < nst) stage_load(st + 1);
+            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
+                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 3] = __builtin_amdgcn_s_memtime();
             if (!wave_active) continue;                       // this wave's 16 pixels lie outside the map
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int kx = 0; kx < 3; ++kx) {
+                    // all ten LDS reads of a tap first, then its eight MFMAs (hipcc otherwise emits
+                    // read -> lgkmcnt(0) -> MFMA chains and exposes the LDS latency per k-step)
+                    float bq[2], aq[2][4];
 #pragma unroll
                     for (int k4 = 0; k4 < 2; ++k4) {
-                        const float b = ldsB[bofl + k4 * 4 * L16_PS + ky * L16_IW + kx];
+                        bq[k4] = ldsB[bofl + k4 * 4 * L16_PS + ky * L16_IW + kx];
                         const float* ap = ldsA + (((ky * 3 + kx) * 2 + k4) * 4) * 64 + lane;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[q * 64], b, acc[q], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) aq[k4][q] = ap[q * 64];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k4][q], bq[k4], acc[q], 0, 0, 0);
+                }
         }
     }
 
