@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
             // loads per thread was waiting on (measured: 3-4k cycles just to issue them)
 #pragma unroll
             for (int k = 0; k < L16_AK4; ++k) {
-                const int i4 = min(tid + k * 256, L16_AFL / 4 - 1);
-                aw[k] = reinterpret_cast<const float4*>(wsrc)[i4];
+                const int i4 = tid + k * 256;
+                aw[k] = (i4 < L16_AFL / 4) ? reinterpret_cast<const float4*>(wsrc)[i4] : float4{0.f, 0.f, 0.f, 0.f};
             }
             const float* cb = inb + (long)st * L16_CK * HW;
 #pragma unroll
