@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbde2vid.so')
+LIB_PATH = os.environ.get('BDE_LIB_PATH') or os.path.join(_HERE, 'libbde2vid.so')   # override: A/B benchmarking of two builds
 
 MAX_LEVELS = 8
 MAX_FRAMES = 8
