@@ -167,6 +167,12 @@ def main():
         fl = lstm_flops_per_launch(cfg, B, H, W, level)
         avg_s = (ms.value / max(cnt.value, 1)) * 1e-3
         achieved = fl / avg_s / 1e12 if avg_s > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (raw counters)
+            with open(os.path.join(REPO, 'profiles', 'r1_lstm0_pmc.json')) as f:
+                traffic = json.load(f)['hbm_bytes_per_launch_raw']
+        except Exception:
+            pass
         out = {
             'metric': 'reconstructed frames/sec at 5x240x180 voxels, seq_len=16',
             'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
@@ -177,9 +183,9 @@ def main():
                                    f'random-init formula weights, one independent sequence per step per GPU',
                        'seq_len': T, 'height': args.height, 'width': args.width, 'batch': B,
                        'parallelism': f'{world} replicas, sequences sharded, 1 RCCL weight broadcast'},
-            'roofline': {'kernel': 'conv_mfma_kernel<3,1,4,1,8,splitK,LSTM> (level-0 ConvLSTM step, both directions)',
+            'roofline': {'kernel': 'lstm16_step_kernel<1,64> (level-0 recurrent ConvLSTM step, both directions)',
                          'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'launches': int(cnt.value), 'avg_us': avg_s * 1e6, 'flops_per_launch': fl},
             'voxelize': {'events_per_s': n_events / vox_dt, 'events': n_events,
                          'note': 'HIP scatter incl. H2D of the events; outside the timed region'},
