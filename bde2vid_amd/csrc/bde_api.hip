@@ -283,7 +283,11 @@ struct Workspace {
     std::vector<float*> xenc, gx, hseq, cst, merged, kvun, kvref, dec, qkv0;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
+    hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
+    bool warm = false;
     void release() {
+        if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        warm = false;
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         T = B = H = W = 0;
@@ -306,7 +310,20 @@ struct bde_model {
     std::vector<PackedLayer> enc, gx, lstm, dec;   // enc/gx/lstm: G=2 (fwd,bwd)
     std::vector<AttnLevel> attn;
     long predw_off = -1, predb_off = -1;
-    Workspace ws;
+    // Workspace slots: slot 0 always; with pipeline depth 2 consecutive forward calls alternate between
+    // two workspaces and two internal streams, so the latency-bound attention chain of one sequence
+    // overlaps the batched convolutions of the next (the sequences are independent, bde2vid.py:31).
+    static constexpr int MAX_SLOTS = 4;
+    Workspace wslots[MAX_SLOTS];
+    int cur = 0;
+    Workspace& W() { return wslots[cur]; }
+    hipStream_t cap_stream = nullptr;
+    int use_graph = 1;                   // replay the captured launch sequence from the second call of a shape on
+    int pipeline = 1;                    // 1 = every call runs on the caller's stream (default); 2 = double-buffered
+    hipStream_t pstream[MAX_SLOTS] = {};
+    hipEvent_t pin[MAX_SLOTS] = {}, pout[MAX_SLOTS] = {};
+    bool pbusy[MAX_SLOTS] = {};
+    long ncalls = 0;
     int device = 0;
     // optional HIP-event timing of tagged launches / stages (bde_profile_*)
     // side stream: per-frame work that only depends on already-refined frames (next level's encoder /
@@ -646,7 +663,7 @@ static int ws_alloc(Workspace& ws, float** p, long numel) {
 }
 
 static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
-    Workspace& ws = m->ws;
+    Workspace& ws = m->W();
     if (ws.T == T && ws.B == B && ws.H == H && ws.W == W) return BDE_OK;
     ws.release();
     const bde_config& c = m->cfg;
@@ -696,7 +713,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
 // Non-recurrent part of a level for frames [f0, f0+nf) of the [TB] stack: encoder conv (both
 // directions read the same sequence, V5.py:124-130) and the x-part of the gates.
 static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int T, int B, int H, int W, hipStream_t s) {
-    Workspace& ws = m->ws;
+    Workspace& ws = m->W();
     const int Cin = m->cin(l), C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
     ConvCall e;
@@ -727,7 +744,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
 
 static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int B, int H, int W, hipStream_t s,
                                bool enc_done = false) {
-    Workspace& ws = m->ws;
+    Workspace& ws = m->W();
     const int C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
     if (!enc_done) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
@@ -788,7 +805,7 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
                                float* out, int B, int H, int W, int blk0, int nblk, const float* qkv_first,
                                hipStream_t s) {
     const bde_config& c = m->cfg;
-    Workspace& ws = m->ws;
+    Workspace& ws = m->W();
     const AttnLevel& al = m->attn[l];
     const int C = al.C, D = c.frame_num;
     const long HW = (long)H * W;
@@ -873,7 +890,7 @@ typedef int (*FrameDoneFn)(bde_model* m, int t, void* ctx);
 static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, hipStream_t s,
                                FrameDoneFn on_frame = nullptr, void* ctx = nullptr) {
     const bde_config& c = m->cfg;
-    Workspace& ws = m->ws;
+    Workspace& ws = m->W();
     const AttnLevel& al = m->attn[l];
     const int C = al.C, D = c.frame_num;
     const long HW = (long)H * W, fs = (long)B * C * HW;
@@ -909,10 +926,10 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
                        hipStream_t s) {
     const PackedLayer& pl = m->dec[j];
-    BDE_TRY(upsample2x_sum(in, skip, m->ws.up, Hs, Ws, (long)N * pl.Cin, s));
+    BDE_TRY(upsample2x_sum(in, skip, m->W().up, Hs, Ws, (long)N * pl.Cin, s));
     ConvCall d;
     d.pl = &pl;
-    d.in = m->ws.up;
+    d.in = m->W().up;
     d.out = out;
     d.N = N;
     d.Hs = 2 * Hs;
@@ -935,18 +952,83 @@ static int check_dims(const bde_model* m, int T, int B, int H, int W) {
     return BDE_OK;
 }
 
+static int forward_on(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
+                      hipStream_t s);
+
+// Pipelined dispatch: call i runs on internal stream i%depth with workspace i%depth.  Inputs are ordered
+// after the caller's stream by an event; outputs are ordered back by bde_wait_outputs (or by the
+// next call that reuses the slot).
 static int forward_impl(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
-                        hipStream_t s) {
+                        hipStream_t user) {
+    if (m->pipeline < 2) {
+        m->cur = 0;
+        return forward_on(m, events, T, B, H, W, images, user);
+    }
+    const int slot = (int)(m->ncalls++ % m->pipeline);
+    if (!m->pstream[slot]) {
+        BDE_HIP(hipStreamCreateWithFlags(&m->pstream[slot], hipStreamNonBlocking));
+        BDE_HIP(hipEventCreateWithFlags(&m->pin[slot], hipEventDisableTiming));
+        BDE_HIP(hipEventCreateWithFlags(&m->pout[slot], hipEventDisableTiming));
+    }
+    m->cur = slot;
+    BDE_HIP(hipEventRecord(m->pin[slot], user));
+    BDE_HIP(hipStreamWaitEvent(m->pstream[slot], m->pin[slot], 0));
+    const int st = forward_on(m, events, T, B, H, W, images, m->pstream[slot]);
+    BDE_HIP(hipEventRecord(m->pout[slot], m->pstream[slot]));
+    m->pbusy[slot] = true;
+    m->cur = 0;
+    return st;
+}
+
+// Everything between the input copy and the output copy: pointers depend only on the workspace,
+// so the launch sequence can be captured once per (slot, T, B, H, W) into a hipGraph and replayed
+// (~1300 launches per forward at config A; replay removes their host cost).
+static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s);
+
+static int forward_on(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
+                      hipStream_t s) {
     BDE_TRY(check_dims(m, T, B, H, W));
     BDE_TRY(ensure_workspace(m, T, B, H, W));
-    ProfScope whole(m, "forward", s);
-    const bde_config& c = m->cfg;
-    Workspace& ws = m->ws;
-    const int L = c.num_encoders;
-    const long TB = (long)T * B;
-    const long ev_fs = (long)B * c.num_bins * H * W, img_fs = (long)B * H * W;
+    Workspace& ws = m->W();
+    const long ev_fs = (long)B * m->cfg.num_bins * H * W, img_fs = (long)B * H * W;
     for (int t = 0; t < T; ++t)
         BDE_HIP(hipMemcpyAsync(ws.ev + t * ev_fs, events[t], sizeof(float) * ev_fs, hipMemcpyDeviceToDevice, s));
+    const bool can_graph = m->use_graph && !m->overlap && ws.warm;   // (profiling spans are captured as event-record nodes)
+    if (can_graph && !ws.graph_exec) {
+        // capture on a private stream (the caller's may be the legacy default stream, which cannot
+        // capture); the instantiated graph is then launched on the caller's stream
+        if (!m->cap_stream) BDE_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        BDE_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        const int st = forward_body(m, T, B, H, W, m->cap_stream);
+        const hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+        hipError_t ei = hipSuccess;
+        if (st == BDE_OK && e == hipSuccess) ei = hipGraphInstantiate(&ws.graph_exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (st != BDE_OK || e != hipSuccess || ei != hipSuccess) {
+            // capture is an optimisation: fall back to eager launches for good
+            (void)hipGetLastError();
+            ws.graph_exec = nullptr;
+            m->use_graph = 0;
+        }
+    }
+    if (m->use_graph && can_graph && ws.graph_exec) {
+        BDE_HIP(hipGraphLaunch(ws.graph_exec, s));
+    } else {
+        BDE_TRY(forward_body(m, T, B, H, W, s));
+        ws.warm = true;                       // first call of a shape runs eagerly (one-time kernel attribute setup)
+    }
+    for (int t = 0; t < T; ++t)
+        BDE_HIP(hipMemcpyAsync(images[t], ws.out + t * img_fs, sizeof(float) * img_fs, hipMemcpyDeviceToDevice, s));
+    return BDE_OK;
+}
+
+static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s) {
+    ProfScope whole(m, "forward", s);
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->W();
+    const int L = c.num_encoders;
+    const long TB = (long)T * B;
     // A. head (V5.py:116)
     ConvCall hc;
     hc.pl = &m->head;
@@ -963,7 +1045,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     struct SideCtx { int l, T, B, H, W; hipStream_t main, side; bool last; int chunk; };
     auto decode_frames = [](bde_model* mm, int f0, int nf, int T_, int B_, int H_, int W_, hipStream_t st) -> int {
         // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x); img = act(predI(x + head))
-        Workspace& w = mm->ws;
+        Workspace& w = mm->W();
         const int L_ = mm->L;
         const float* x = w.merged[L_ - 1] + (long)f0 * mm->cout(L_ - 1) * (H_ >> L_) * (W_ >> L_);
         for (int j = 0; j < L_; ++j) {
@@ -1021,7 +1103,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
                     BDE_HIP(hipStreamWaitEvent(q->side, mm->frame_ev[t], 0));
                     if (q->last) return decode_fn(mm, t0 * q->B, nt * q->B, q->T, q->B, q->H, q->W, q->side);
                     const int ln = q->l + 1;
-                    return run_enc_gx(mm, ln, mm->ws.merged[q->l], t0 * q->B, nt * q->B, q->T, q->B, q->H >> ln, q->W >> ln, q->side);
+                    return run_enc_gx(mm, ln, mm->W().merged[q->l], t0 * q->B, nt * q->B, q->T, q->B, q->H >> ln, q->W >> ln, q->side);
                 };
             }
             BDE_TRY(run_attention_level(m, l, T, B, h, w, s, fn, &sc));
@@ -1034,8 +1116,6 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
         target = ws.merged[l];
     }
     if (!decoded) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s));
-    for (int t = 0; t < T; ++t)
-        BDE_HIP(hipMemcpyAsync(images[t], ws.out + t * img_fs, sizeof(float) * img_fs, hipMemcpyDeviceToDevice, s));
     return BDE_OK;
 }
 
@@ -1084,7 +1164,13 @@ int bde_create(const bde_config* cfg, bde_model** out) {
 
 void bde_destroy(bde_model* m) {
     if (!m) return;
-    m->ws.release();
+    for (auto& w : m->wslots) w.release();
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    for (int i = 0; i < bde_model::MAX_SLOTS; ++i) {
+        if (m->pin[i]) (void)hipEventDestroy(m->pin[i]);
+        if (m->pout[i]) (void)hipEventDestroy(m->pout[i]);
+        if (m->pstream[i]) (void)hipStreamDestroy(m->pstream[i]);
+    }
     if (m->dev) (void)hipFree(m->dev);
     for (auto& sp : m->prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : m->prof_pool) (void)hipEventDestroy(e);
@@ -1173,8 +1259,26 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
     return forward_impl(m, events, T, B, Hp, Wp, images, (hipStream_t)stream);
 }
 
+int bde_wait_outputs(bde_model* m, void* stream) {
+    BDE_REQUIRE(m != nullptr, "null model");
+    for (int i = 0; i < bde_model::MAX_SLOTS; ++i)
+        if (m->pbusy[i]) {
+            BDE_HIP(hipStreamWaitEvent((hipStream_t)stream, m->pout[i], 0));
+            m->pbusy[i] = false;
+        }
+    return BDE_OK;
+}
+
 int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     BDE_REQUIRE(m && key, "null argument");
+    if (std::string(key) == "graph") { m->use_graph = (int)value; return BDE_OK; }
+    if (std::string(key) == "pipeline") {
+        BDE_REQUIRE(value >= 1 && value <= bde_model::MAX_SLOTS, "pipeline depth must be 1..%d", bde_model::MAX_SLOTS);
+        m->pipeline = (int)value;
+        return BDE_OK;
+    }
+    for (auto& w : m->wslots)
+        if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }
@@ -1215,6 +1319,8 @@ int bde_profile_reset(bde_model* m, int32_t enable) {
     for (auto& sp : m->prof) { m->prof_pool.push_back(sp.a); m->prof_pool.push_back(sp.b); }
     m->prof.clear();
     m->prof_on = enable != 0;
+    for (auto& w : m->wslots)          // spans live inside the captured graph: re-capture
+        if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
     return BDE_OK;
 }
 
@@ -1237,7 +1343,7 @@ int bde_profile_get(bde_model* m, const char* name, double* total_ms, int64_t* c
 
 int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream) {
     BDE_REQUIRE(m && name && dst, "null argument");
-    Workspace& ws = m->ws;
+    Workspace& ws = m->W();
     BDE_REQUIRE(ws.T > 0, "no forward has run");
     const long TB = (long)ws.T * ws.B;
     const float* src = nullptr;
@@ -1313,10 +1419,10 @@ int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float*
     const int C = m->cout(level);
     const long hw = (long)(H / 2) * (W / 2), TB = (long)T * B;
     // dir 0 sweeps t = 0..T-1, dir 1 sweeps t = T-1..0 (V5.py:123); h_out[t] belongs to input frame t.
-    BDE_HIP(hipMemcpyAsync(h_out, m->ws.hseq[level] + (long)dir * TB * C * hw, sizeof(float) * TB * C * hw,
+    BDE_HIP(hipMemcpyAsync(h_out, m->W().hseq[level] + (long)dir * TB * C * hw, sizeof(float) * TB * C * hw,
                            hipMemcpyDeviceToDevice, s));
     if (c_out)
-        BDE_HIP(hipMemcpyAsync(c_out, m->ws.cst[level] + (long)dir * B * C * hw, sizeof(float) * B * C * hw,
+        BDE_HIP(hipMemcpyAsync(c_out, m->W().cst[level] + (long)dir * B * C * hw, sizeof(float) * B * C * hw,
                                hipMemcpyDeviceToDevice, s));
     return BDE_OK;
 }
@@ -1361,7 +1467,7 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
     for (int d = 0; d < D; ++d) {
         kvslot[d] = nullptr;
         if (d == c.q_idx || bufs[d] == nullptr) continue;
-        float* dst = m->ws.kvun[level] + (long)d * kvfs;
+        float* dst = m->W().kvun[level] + (long)d * kvfs;
         BDE_TRY(run_pw(m, &al.kvall, bufs[d], dst, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
         kvslot[d] = dst;
     }

@@ -15,8 +15,10 @@ import torch.distributed as dist
 def init_from_env(backend: str = None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); no-op single process."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not os.environ.get('BDE_FORCE_DIST'):   # (BDE_FORCE_DIST: exercise RCCL with one rank)
         return 0, 1, 0
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('MASTER_PORT', '29500')
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
@@ -38,7 +40,7 @@ def shard_sequences(n_sequences: int, rank: int, world: int) -> List[int]:
 
 def broadcast_packed(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
     """Broadcast a flat fp32 weight image in place (RCCL on GPUs, gloo in the CPU tests)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('BDE_FORCE_DIST')):
         dist.broadcast(flat, src=src)
     return flat
 
@@ -53,7 +55,7 @@ def build_replicated_model(cfg, state_dict_fn, device):
         m.load_state_dict(state_dict_fn())
     else:
         m.alloc_packed()
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('BDE_FORCE_DIST')):
         broadcast_packed(m.packed_view(), 0)
         torch.cuda.synchronize(device)
     return m

@@ -154,6 +154,12 @@ class BDE2VID:
                                               C.c_void_p(_stream_ptr(dev))))
         return [out[t] for t in range(T)]
 
+    def wait(self):
+        """Pipelined mode only (set_tuning('pipeline', 2)): order the outputs of all forward calls issued so
+        far into the current stream.  Call before reading them (a device synchronize also suffices)."""
+        _lib.check(_lib.lib().bde_wait_outputs(self._h, C.c_void_p(_stream_ptr(self.device))))
+        return self
+
     def set_tuning(self, key: str, value: int):
         _lib.check(_lib.lib().bde_set_tuning(self._h, key.encode(), int(value)))
         return self

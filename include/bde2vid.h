@@ -91,7 +91,16 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
  * (level output after attention), "dec<j>".  Layout [T][B][C][H][W]. */
 int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream);
 
+/* Pipelined mode ("pipeline" = 2..4, see bde_set_tuning): consecutive bde_forward calls (independent
+ * sequences) rotate over that many internal streams and workspaces; inputs are ordered after the
+ * caller's `stream`, but the outputs of a call are only ordered into `stream` by bde_wait_outputs
+ * (call it before anything on `stream` reads them).  Default is "pipeline" = 1: no such call needed. */
+int bde_wait_outputs(bde_model* m, void* stream);
+
 /* Scheduling knobs (results are unchanged up to fp32 summation order).  Keys:
+ *   "pipeline": 1 (default) .. 4 sequences in flight per model object, see bde_wait_outputs.
+ *   "graph": 1 (default) replays the launch sequence of a forward from a hipGraph captured at the second
+ *              call of a shape; 0 launches eagerly.
  *   "fused_min_tiles": a level with at least this many 32-pixel tiles runs the post-softmax part of an
  *                      attention block as one fused kernel instead of three GEMM launches (default 160). */
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);

@@ -133,9 +133,13 @@ print('rank', rank, 'ok', mine)
 def test_two_rank_gloo_sharding_and_weight_broadcast(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER % REPO)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    import socket
+    with socket.socket() as sk:           # a free port: fixed ports collide with sockets in TIME_WAIT
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+                        '--master-addr', '127.0.0.1', '--master-port', port, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout
