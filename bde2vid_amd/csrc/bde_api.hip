@@ -1281,6 +1281,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_shape") { lstm16_shape_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_debug") { m->tok_debug = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap") { m->overlap = (int)value; return BDE_OK; }
@@ -1307,6 +1308,7 @@ int bde_debug_occupancy(const char* kernel) {
     std::string k(kernel ? kernel : "");
     hipError_t e = hipErrorInvalidValue;
     if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64>, 256, 0);
+    else if (k == "lstm16_1_128") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 128>, 512, 0);
     else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32>, 256, 0);
     else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64));
     else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, conv_maxi(3)>, 256, 42 * 1024);

@@ -24,19 +24,22 @@ typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 constexpr int L16_CK = 8;                        // channels per stage
 constexpr int L16_AFL = 9 * 2 * 4 * 64;          // floats of one stage's weight fragments (18 KiB)
-constexpr int L16_AK4 = (L16_AFL / 4 + 255) / 256;  // 16-byte loads per thread (5; 1152 float4 per stage)
 // plane stride of the halo tile, padded to 16 (mod 32) floats
 constexpr int l16_ps(int rows, int pxw) { return ((rows + 2) * (pxw + 2) + 15) / 32 * 32 + 16; }
 
-// A workgroup covers ROWS image rows x PXW pixels (ROWS*PXW = 64; one 16-pixel segment per wave):
-// <1,64> for wide maps, <2,32> / <4,16> for narrow ones so that all four waves have pixels.
+// A workgroup covers ROWS image rows x PXW pixels, one 16-pixel segment per wave (ROWS*PXW/16 waves:
+// 4 or 8): <1,64> / <1,128> for wide maps, <2,32> / <4,16> / <2,64> ... for narrow ones so that all
+// waves have pixels.  Eight waves share one stage's weight fragments: half the L2->LDS weight traffic
+// per pixel, which is what the stage prefetch was queueing behind.
 // Uses the ConvArgs fields of EPI_LSTM (in = h_prev, out = h, gx, cstate, first, strides).
 template <int ROWS, int PXW>
-__global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvArgs a) {
+    constexpr int NT = ROWS * PXW * 4;               // threads per workgroup (64 per 16-pixel segment)
+    constexpr int L16_AK4 = (L16_AFL / 4 + NT - 1) / NT;   // 16-byte weight loads per thread and stage
     constexpr int L16_IW = PXW + 2;
     constexpr int L16_R = ROWS + 2;
     constexpr int L16_PS = l16_ps(ROWS, PXW);
-    constexpr int L16_BK = (L16_CK * L16_R * L16_IW + 255) / 256;
+    constexpr int L16_BK = (L16_CK * L16_R * L16_IW + NT - 1) / NT;
     constexpr int XT = PXW / 16;                     // waves along x
     __shared__ __align__(16) float ldsA[L16_AFL];
     __shared__ __align__(16) float ldsB[L16_CK * L16_PS];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
         unsigned bmask = 0;
 #pragma unroll
         for (int k = 0; k < L16_BK; ++k) {
-            const int e = tid + k * 256;
+            const int e = tid + k * NT;
             const int ci = e / (L16_R * L16_IW), rem = e - ci * (L16_R * L16_IW);
             const int r = rem / L16_IW, col = rem - r * L16_IW;
             const int iy = y0 - 1 + r, ix = x0 - 1 + col;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
             // loads per thread was waiting on (measured: 3-4k cycles just to issue them)
 #pragma unroll
             for (int k = 0; k < L16_AK4; ++k) {
-                const int i4 = tid + k * 256;
+                const int i4 = tid + k * NT;
                 aw[k] = (i4 < L16_AFL / 4) ? reinterpret_cast<const float4*>(wsrc)[i4] : float4{0.f, 0.f, 0.f, 0.f};
             }
             const float* cb = inb + (long)st * L16_CK * HW;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
                 a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int k = 0; k < L16_AK4; ++k) {
-                const int i4 = tid + k * 256;
+                const int i4 = tid + k * NT;
                 if (i4 < L16_AFL / 4) reinterpret_cast<float4*>(ldsA)[i4] = aw[k];
             }
 #pragma unroll
@@ -171,25 +174,42 @@ __global__ __launch_bounds__(256) void lstm16_step_kernel(const ConvArgs a) {
     }
 }
 
+inline int& lstm16_shape_ref() { static int v = 0; return v; }   // tuning: rows*1000 + pxw, 0 = auto
+
 template <int ROWS, int PXW>
 static int lstm16_launch_t(const ConvArgs& a, hipStream_t stream) {
     const int Ch = a.Cout / 4;
     dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, 16), 2 * a.N);
-    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW>), grid, dim3(ROWS * PXW * 4), 0, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 
 static int lstm16_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.Cin % L16_CK != 0) return fail(BDE_ERR_UNSUPPORTED, "recurrent step: %d hidden channels is not a multiple of %d", a.Cin, L16_CK);
-    // tile shape with the most active 16-pixel wave segments per launched wave
+    // tile shape with the most active 16-pixel wave segments per launched wave; the 8-wave shapes
+    // (twice the pixels per weight fetch) are used only where they fill strictly better
     auto fill = [&](int rows, int pxw) {
         const double segs = (double)a.Ho * cdiv(a.Wo, 16);
-        return segs / ((double)cdiv(a.Ho, rows) * rows * cdiv(a.Wo, pxw) * (pxw / 16));
+        return segs / ((double)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * (rows * pxw / 16));
     };
-    const double f1 = fill(1, 64), f2 = fill(2, 32), f4 = fill(4, 16);
-    if (f1 >= f2 - 0.02 && f1 >= f4 - 0.02) return lstm16_launch_t<1, 64>(a, stream);
-    if (f2 >= f4 - 0.02) return lstm16_launch_t<2, 32>(a, stream);
+    auto blocks = [&](int rows, int pxw) { return (long)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * cdiv(a.Cout / 4, 16) * 2 * a.N; };
+    int force = lstm16_shape_ref();
+    struct Shape { int rows, pxw; };
+    const Shape big[] = {{1, 128}, {2, 64}, {4, 32}}, small[] = {{1, 64}, {2, 32}, {4, 16}};
+    Shape best{1, 64};
+    double bf = -1;
+    for (const Shape& sh : small) { const double f = fill(sh.rows, sh.pxw); if (f > bf + 0.02) { bf = f; best = sh; } }
+    for (const Shape& sh : big) {
+        const double f = fill(sh.rows, sh.pxw);
+        if (f > bf + 0.02 && blocks(sh.rows, sh.pxw) >= 512) { bf = f; best = sh; }   // (measured: no gain at equal fill)
+    }
+    if (force) best = Shape{force / 1000, force % 1000};
+    if (best.rows == 1 && best.pxw == 128) return lstm16_launch_t<1, 128>(a, stream);
+    if (best.rows == 2 && best.pxw == 64) return lstm16_launch_t<2, 64>(a, stream);
+    if (best.rows == 4 && best.pxw == 32) return lstm16_launch_t<4, 32>(a, stream);
+    if (best.rows == 1 && best.pxw == 64) return lstm16_launch_t<1, 64>(a, stream);
+    if (best.rows == 2 && best.pxw == 32) return lstm16_launch_t<2, 32>(a, stream);
     return lstm16_launch_t<4, 16>(a, stream);
 }
 
