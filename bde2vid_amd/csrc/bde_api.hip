@@ -784,7 +784,6 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         a.Ho = h;
         a.Wo = w;
         a.nchunks = pl.nchunks;
-        a.dbg_stamps = (l == 0 && st == T - 1) ? m->tok_stamps : nullptr;   // diagnostics (bde_debug_token_stamps)
         {
             static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
             ProfScope ps(m, names[l], s);
@@ -1307,9 +1306,9 @@ int bde_debug_occupancy(const char* kernel) {
     int nb = -1;
     std::string k(kernel ? kernel : "");
     hipError_t e = hipErrorInvalidValue;
-    if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64>, 256, 0);
-    else if (k == "lstm16_1_128") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 128>, 512, 0);
-    else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32>, 256, 0);
+    if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 1>, 256, 0);
+    else if (k == "lstm16_1_64_hb2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 2>, 256, 0);
+    else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32, 1>, 256, 0);
     else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64));
     else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, conv_maxi(3)>, 256, 42 * 1024);
     if (e != hipSuccess) return -1;

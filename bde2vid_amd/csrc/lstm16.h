@@ -28,20 +28,23 @@ constexpr int L16_AFL = 9 * 2 * 4 * 64;          // floats of one stage's weight
 constexpr int l16_ps(int rows, int pxw) { return ((rows + 2) * (pxw + 2) + 15) / 32 * 32 + 16; }
 
 // A workgroup covers ROWS image rows x PXW pixels, one 16-pixel segment per wave (ROWS*PXW/16 waves:
-// 4 or 8): <1,64> / <1,128> for wide maps, <2,32> / <4,16> / <2,64> ... for narrow ones so that all
-// waves have pixels.  Eight waves share one stage's weight fragments: half the L2->LDS weight traffic
-// per pixel, which is what the stage prefetch was queueing behind.
+// 4 or 8), and HB blocks of 16 hidden channels.  <1,64> for wide maps, <2,32> / <4,16> for narrow ones
+// so that all waves have pixels.  In-kernel stamps (level 0 of config A): ~80 % MFMA duty while four
+// workgroups share a CU, 54 % for a workgroup alone; the launch is 1472 workgroups on 1024 resident
+// slots, and the second, thinly populated round costs about a quarter of it.  HB = 2 (half the waves,
+// one round) was built to fix that but needs 176 registers -> 2 waves/SIMD, and measured slower.
 // Uses the ConvArgs fields of EPI_LSTM (in = h_prev, out = h, gx, cstate, first, strides).
-template <int ROWS, int PXW>
+template <int ROWS, int PXW, int HB>
 __global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvArgs a) {
     constexpr int NT = ROWS * PXW * 4;               // threads per workgroup (64 per 16-pixel segment)
-    constexpr int L16_AK4 = (L16_AFL / 4 + NT - 1) / NT;   // 16-byte weight loads per thread and stage
+    constexpr int AFL4 = HB * L16_AFL / 4;           // float4 of one stage's weight fragments
+    constexpr int L16_AK4 = (AFL4 + NT - 1) / NT;    // 16-byte weight loads per thread and stage
     constexpr int L16_IW = PXW + 2;
     constexpr int L16_R = ROWS + 2;
     constexpr int L16_PS = l16_ps(ROWS, PXW);
     constexpr int L16_BK = (L16_CK * L16_R * L16_IW + NT - 1) / NT;
     constexpr int XT = PXW / 16;                     // waves along x
-    __shared__ __align__(16) float ldsA[L16_AFL];
+    __shared__ __align__(16) float ldsA[HB * L16_AFL];
     __shared__ __align__(16) float ldsB[L16_CK * L16_PS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.z;
@@ -50,20 +53,23 @@ __global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvA
     const int tiles_x = (W + PXW - 1) / PXW;
     const int ty = blockIdx.x / tiles_x;
     const int y0 = ty * ROWS, x0 = (blockIdx.x - ty * tiles_x) * PXW;
-    const int hb = blockIdx.y;
+    const int hb0 = blockIdx.y * HB;                         // first hidden16 block of this workgroup
+    const int nhb = (Ch + 15) / 16;
     const int wrow = wave / XT, wx = wave - wrow * XT;       // this wave's row and 16-pixel segment
     const int pxl = wx * 16 + (lane & 15);                   // x of this lane inside the tile
     const int y = y0 + wrow;
     const bool pvalid = (x0 + pxl) < W && y < H;
     const bool wave_active = (x0 + wx * 16) < W && y < H;
 
-    f32x4_ acc[4];
+    f32x4_ acc[HB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < HB; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[h][q] = f32x4_{0.f, 0.f, 0.f, 0.f};
 
     if (!a.first) {
         const float* inb = a.in + g * a.in_gs + n * a.in_ns;
-        const float* wg = a.wpk + g * a.w_gs + (long)hb * a.nchunks * L16_AFL;
+        const float* wgrp = a.wpk + g * a.w_gs;
         // fixed staging slots of this thread for the halo tile: element e = (ci, r, col)
         int boffs[L16_BK];
         unsigned bsrc[L16_BK];
@@ -80,68 +86,66 @@ __global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvA
             if (ok) bmask |= 1u << k;
             bsrc[k] = ok ? (unsigned)(ci * HW + iy * W + ix) : 0u;
         }
+        // weight staging slot k of this thread: float4 index i4 inside the HB stacked fragment blocks
         float4 aw[L16_AK4];
         float bw[L16_BK];
         auto stage_load = [&](int st) {
-            const float* wsrc = wg + (long)st * L16_AFL;
-            // 16-byte loads: the vector-memory issue slot, not bandwidth, is what a stage of 25 dword
-            // loads per thread was waiting on (measured: 3-4k cycles just to issue them)
+            // 16-byte loads (a stage of dword loads queued for thousands of cycles on the VMEM path)
 #pragma unroll
             for (int k = 0; k < L16_AK4; ++k) {
                 const int i4 = tid + k * NT;
-                aw[k] = (i4 < L16_AFL / 4) ? reinterpret_cast<const float4*>(wsrc)[i4] : float4{0.f, 0.f, 0.f, 0.f};
+                const int h = i4 / (L16_AFL / 4), r4 = i4 - h * (L16_AFL / 4);
+                const int hbc = min(hb0 + h, nhb - 1);       // (a padded hidden block re-reads the last one)
+                const float4* wsrc = reinterpret_cast<const float4*>(wgrp + ((long)hbc * a.nchunks + st) * L16_AFL);
+                aw[k] = (i4 < AFL4) ? wsrc[r4] : float4{0.f, 0.f, 0.f, 0.f};
             }
             const float* cb = inb + (long)st * L16_CK * HW;
+            // exec-masked loads: fastest of the three zero-padding forms tried (select at load time,
+            // select at LDS-store time, masked load)
 #pragma unroll
-            // (measured: the L2 round trip under this kernel's load is 4-5k cycles, longer than one
-            //  stage, so a one-stage register prefetch cannot hide it whichever way the zero-padding
-            //  select is placed; this form -- exec-masked loads -- was the fastest of the three tried)
             for (int k = 0; k < L16_BK; ++k) bw[k] = ((bmask >> k) & 1u) ? cb[bsrc[k]] : 0.f;
         };
         const int bofl = (lane >> 4) * L16_PS + wrow * L16_IW + pxl;   // tap (0,0), k4 = 0
         const int nst = a.nchunks;
         stage_load(0);
         for (int st = 0; st < nst; ++st) {
-            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
-                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 0] = __builtin_amdgcn_s_memtime();
             __syncthreads();
-            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
-                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int k = 0; k < L16_AK4; ++k) {
                 const int i4 = tid + k * NT;
-                if (i4 < L16_AFL / 4) reinterpret_cast<float4*>(ldsA)[i4] = aw[k];
+                if (i4 < AFL4) reinterpret_cast<float4*>(ldsA)[i4] = aw[k];
             }
 #pragma unroll
             for (int k = 0; k < L16_BK; ++k)
                 if (boffs[k] >= 0) ldsB[boffs[k]] = bw[k];
             __syncthreads();
-            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
-                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 2] = __builtin_amdgcn_s_memtime();
             if (st + 1 < nst) stage_load(st + 1);
-            if (a.dbg_stamps && lane == 0 && blockIdx.x < 16 && blockIdx.y == 0 && blockIdx.z == 0 && st < 8)
-                a.dbg_stamps[((blockIdx.x * 4 + wave) * 8 + st) * 4 + 3] = __builtin_amdgcn_s_memtime();
             if (!wave_active) continue;                       // this wave's 16 pixels lie outside the map
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    // all ten LDS reads of a tap first, then its eight MFMAs (hipcc otherwise emits
+                    // all LDS reads of a tap first, then its MFMAs (hipcc otherwise emits
                     // read -> lgkmcnt(0) -> MFMA chains and exposes the LDS latency per k-step)
-                    float bq[2], aq[2][4];
+                    float bq[2], aq[HB][2][4];
 #pragma unroll
                     for (int k4 = 0; k4 < 2; ++k4) {
                         bq[k4] = ldsB[bofl + k4 * 4 * L16_PS + ky * L16_IW + kx];
-                        const float* ap = ldsA + (((ky * 3 + kx) * 2 + k4) * 4) * 64 + lane;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) aq[k4][q] = ap[q * 64];
+                        for (int h = 0; h < HB; ++h) {
+                            const float* ap = ldsA + h * L16_AFL + (((ky * 3 + kx) * 2 + k4) * 4) * 64 + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) aq[h][k4][q] = ap[q * 64];
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k4][q], bq[k4], acc[q], 0, 0, 0);
+                        for (int h = 0; h < HB; ++h)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[h][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[h][k4][q], bq[k4], acc[h][q], 0, 0, 0);
                 }
         }
     }
@@ -152,65 +156,67 @@ __global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvA
     float* hout = a.out + g * a.out_gs + n * a.out_ns;
     float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
     const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
-    float gv[4][4], cprev[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int hc = min(hb * 16 + (lane >> 4) * 4 + r, Ch - 1);
-        const long o = (long)hc * HW + p;
+    for (int h = 0; h < HB; ++h) {
+        float gv[4][4], cprev[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gv[q][r] = gxb[(long)q * Ch * HW + o];
-        cprev[r] = a.first ? 0.f : cst[o];
-    }
+        for (int r = 0; r < 4; ++r) {
+            const int hc = min((hb0 + h) * 16 + (lane >> 4) * 4 + r, Ch - 1);
+            const long o = (long)hc * HW + p;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int hc = hb * 16 + (lane >> 4) * 4 + r;
-        if (hc >= Ch) continue;
-        const long o = (long)hc * HW + p;
-        const float gi = acc[0][r] + gv[0][r], gf = acc[1][r] + gv[1][r];
-        const float go = acc[2][r] + gv[2][r], gg = acc[3][r] + gv[3][r];
-        const float c = sigmoidf_(gf) * cprev[r] + sigmoidf_(gi) * tanhf(gg);
-        cst[o] = c;
-        hout[o] = sigmoidf_(go) * tanhf(c);
+            for (int q = 0; q < 4; ++q) gv[q][r] = gxb[(long)q * Ch * HW + o];
+            cprev[r] = a.first ? 0.f : cst[o];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hc = (hb0 + h) * 16 + (lane >> 4) * 4 + r;
+            if (hc >= Ch) continue;
+            const long o = (long)hc * HW + p;
+            const float gi = acc[h][0][r] + gv[0][r], gf = acc[h][1][r] + gv[1][r];
+            const float go = acc[h][2][r] + gv[2][r], gg = acc[h][3][r] + gv[3][r];
+            const float c = sigmoidf_(gf) * cprev[r] + sigmoidf_(gi) * tanhf(gg);
+            cst[o] = c;
+            hout[o] = sigmoidf_(go) * tanhf(c);
+        }
     }
 }
 
-inline int& lstm16_shape_ref() { static int v = 0; return v; }   // tuning: rows*1000 + pxw, 0 = auto
+inline int& lstm16_shape_ref() { static int v = 0; return v; }    // tuning: hb*100000 + rows*1000 + pxw, 0 = auto
 
-template <int ROWS, int PXW>
+template <int ROWS, int PXW, int HB>
 static int lstm16_launch_t(const ConvArgs& a, hipStream_t stream) {
     const int Ch = a.Cout / 4;
-    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, 16), 2 * a.N);
-    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW>), grid, dim3(ROWS * PXW * 4), 0, stream, a);
+    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, 16 * HB), 2 * a.N);
+    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW, HB>), grid, dim3(ROWS * PXW * 4), 0, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 
 static int lstm16_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.Cin % L16_CK != 0) return fail(BDE_ERR_UNSUPPORTED, "recurrent step: %d hidden channels is not a multiple of %d", a.Cin, L16_CK);
-    // tile shape with the most active 16-pixel wave segments per launched wave; the 8-wave shapes
-    // (twice the pixels per weight fetch) are used only where they fill strictly better
+    // tile shape with the most active 16-pixel wave segments per launched wave
     auto fill = [&](int rows, int pxw) {
         const double segs = (double)a.Ho * cdiv(a.Wo, 16);
         return segs / ((double)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * (rows * pxw / 16));
     };
-    auto blocks = [&](int rows, int pxw) { return (long)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * cdiv(a.Cout / 4, 16) * 2 * a.N; };
-    int force = lstm16_shape_ref();
-    struct Shape { int rows, pxw; };
-    const Shape big[] = {{1, 128}, {2, 64}, {4, 32}}, small[] = {{1, 64}, {2, 32}, {4, 16}};
-    Shape best{1, 64};
+    const int shapes[3][2] = {{1, 64}, {2, 32}, {4, 16}};
+    int rows = 1, pxw = 64;
     double bf = -1;
-    for (const Shape& sh : small) { const double f = fill(sh.rows, sh.pxw); if (f > bf + 0.02) { bf = f; best = sh; } }
-    for (const Shape& sh : big) {
-        const double f = fill(sh.rows, sh.pxw);
-        if (f > bf + 0.02 && blocks(sh.rows, sh.pxw) >= 512) { bf = f; best = sh; }   // (measured: no gain at equal fill)
-    }
-    if (force) best = Shape{force / 1000, force % 1000};
-    if (best.rows == 1 && best.pxw == 128) return lstm16_launch_t<1, 128>(a, stream);
-    if (best.rows == 2 && best.pxw == 64) return lstm16_launch_t<2, 64>(a, stream);
-    if (best.rows == 4 && best.pxw == 32) return lstm16_launch_t<4, 32>(a, stream);
-    if (best.rows == 1 && best.pxw == 64) return lstm16_launch_t<1, 64>(a, stream);
-    if (best.rows == 2 && best.pxw == 32) return lstm16_launch_t<2, 32>(a, stream);
-    return lstm16_launch_t<4, 16>(a, stream);
+    for (auto& sh : shapes) { const double f = fill(sh[0], sh[1]); if (f > bf + 0.02) { bf = f; rows = sh[0]; pxw = sh[1]; } }
+    // one hidden16 block per workgroup gives 4 waves/SIMD of residency (1024 workgroups on the chip);
+    // above that, two blocks per workgroup (3 waves/SIMD, 768 workgroups) keep the launch in one round
+    const long wg1 = (long)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * cdiv(a.Cout / 4, 16) * 2 * a.N;
+    (void)wg1;
+    int hb = 1;   // measured: HB = 2 needs 176 registers (2 waves/SIMD) and loses 6-12 % at every level of config A
+    if (const int f = lstm16_shape_ref()) { hb = f / 100000; rows = (f / 1000) % 100; pxw = f % 1000; }
+#define BDE_L16(R_, P_)                                                                  \
+    if (rows == R_ && pxw == P_)                                                         \
+        return hb == 2 ? lstm16_launch_t<R_, P_, 2>(a, stream) : lstm16_launch_t<R_, P_, 1>(a, stream);
+    BDE_L16(1, 64)
+    BDE_L16(2, 32)
+    BDE_L16(4, 16)
+#undef BDE_L16
+    return fail(BDE_ERR_ARG, "recurrent step: tile shape %dx%d not built", rows, pxw);
 }
 
 }  // namespace bde

@@ -7,6 +7,7 @@ from bde2vid_amd.weights import formula_state_dict
 cfg = canonical()
 m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
 L = _lib.lib()
+if os.environ.get('PADLDS'): m.set_tuning('lstm_padlds', int(os.environ['PADLDS']))
 x = torch.randn(4, 1, 32, 184, 240, device='cuda')
 ops.recurrent_conv(m, 0, 0, x); torch.cuda.synchronize()
 L.bde_debug_token_stamps(m._h, None, 0)
