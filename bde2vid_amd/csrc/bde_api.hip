@@ -21,6 +21,7 @@
 #include "pw_gemm.h"
 #include "token_fused.h"
 #include "lstm16.h"
+#include "conv_vec.h"
 #include "voxel.h"
 
 namespace bde {
@@ -629,7 +630,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.w_gs = pl.w_sz;
     a.bias_gs = pl.Cout;
     if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
-    return conv_launch_auto(pl.KS, cc.stride, a, pl.G, s);
+    return conv_launch_best(pl.KS, cc.stride, a, pl.G, s);
 }
 
 // 1x1 conv over flattened [C][HW] planes
@@ -1280,6 +1281,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "conv_vec") { conv_vec_enable_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_shape") { lstm16_shape_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_debug") { m->tok_debug = (int)value; return BDE_OK; }

@@ -14,6 +14,8 @@ cfg = canonical()
 m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
 if os.environ.get('PW_FORCE'):
     m.set_tuning('pw_force', int(os.environ['PW_FORCE']))
+if os.environ.get('CONV_VEC'):
+    m.set_tuning('conv_vec', int(os.environ['CONV_VEC']))
 if os.environ.get('LSTM_SHAPE'):
     m.set_tuning('lstm_shape', int(os.environ['LSTM_SHAPE']))
 if os.environ.get('TOK_NPT'):
