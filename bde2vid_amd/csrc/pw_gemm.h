@@ -219,9 +219,18 @@ static int pw_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 
 // Pick the decomposition of one pointwise GEMM launch: enough waves to cover the 1024 SIMDs,
 // as little reduction as possible.
-inline int& pw_force_ref() { static int v = 0; return v; }   // debug/tuning: mt*100 + nt*10 + ws, 0 = auto
+inline int& pw_force_ref() { static int v = 0; return v; }
+inline int& pw_batched_ref() { static int v = 0; return v; }  // same for the T-batched launches   // debug/tuning: mt*100 + nt*10 + ws, 0 = auto
 
 static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
+    if (const int f = pw_batched_ref(); f != 0 && (long)G * a.N > 4) {
+        switch (f) {
+            case 221: return pw_launch_t<2, 2, 1>(a, G, stream);
+            case 211: return pw_launch_t<2, 1, 1>(a, G, stream);
+            case 111: return pw_launch_t<1, 1, 1>(a, G, stream);
+            default: break;
+        }
+    }
     if (const int f = pw_force_ref(); f != 0 && (long)G * a.N <= 4) {
         switch (f) {
             case 211: return pw_launch_t<2, 1, 1>(a, G, stream);
@@ -236,8 +245,9 @@ static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
     const int kpairs = a.Cin / 2;
     const long t2 = px_tiles * cdiv(a.Cout, 64) * frames;     // wave tasks with MT = 2
     const long t1 = px_tiles * cdiv(a.Cout, 32) * frames;     // wave tasks with MT = 1
-    if (t2 / 2 >= 4096) return pw_launch_t<2, 2, 1>(a, G, stream);   // T-batched: maximise reuse
-    if (t2 >= 2048) return pw_launch_t<2, 1, 1>(a, G, stream);
+    // T-batched launches are bound by their output stores (K is only 64..256): the lean one-tile-per-
+    // wave variant (4 waves/SIMD) measured ahead of the register-heavy 2x2 and 2x1 ones
+    if (t1 >= 768) return pw_launch_t<1, 1, 1>(a, G, stream);
     if (t1 >= 768) return pw_launch_t<1, 1, 1>(a, G, stream);
     // few tiles (one frame of a small map): split K over the waves of a block; one 32x32 tile per
     // wave measured faster than two on the level-2 chain (more blocks, shorter per-wave chains)
