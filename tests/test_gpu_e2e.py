@@ -173,3 +173,21 @@ def test_pipelined_graph_mode_is_bit_identical():
     for r, o in zip(ref, outs):
         assert torch.equal(r, torch.stack(o))
     m.set_tuning('pipeline', 1)
+
+
+def test_checkpoint_file_round_trip(tmp_path):
+    """A file in the reference's checkpoint format ({'state_dict', 'meta': {'cfg': <config source>}},
+    eval_models_seq.py:52-60) loads without mmengine and reproduces the golden frames."""
+    from bde2vid_amd.checkpoint import load_model
+    z, meta = load_golden('e2e_tiny')
+    cfg, sd, xs = case_from_meta(meta)
+    src = ("model = dict(type='BDE2VID', cpu_cache_length=100, generator=dict(type='BDE2VIDCrossscalePropogationV5', "
+           f"num_bins={cfg.num_bins}, basechannels={cfg.basechannels}, num_encoders={cfg.num_encoders}, ks={cfg.ks}, "
+           f"num_res_blocks=2, norm=None, activation=dict(type='Sigmoid'), buffer_index={list(cfg.buffer_index)}, "
+           f"q_idx={cfg.q_idx}, depths={list(cfg.depths)}, num_heads={cfg.num_heads}, losses=[]))")
+    path = tmp_path / 'BDE2VID_epoch_1.pth'
+    torch.save({'state_dict': sd, 'meta': {'cfg': src}}, str(path))
+    m = load_model(str(path), 'cuda:0')
+    with torch.no_grad():
+        y = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in xs]))
+    assert maxabs(y, z['out']) <= TOL

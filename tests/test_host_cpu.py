@@ -144,3 +144,47 @@ def test_two_rank_gloo_sharding_and_weight_broadcast(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     # (ranks report through files: their stdout interleaves)
     assert (tmp_path / 'ok0').read_text() == '[0, 2, 4, 6]' and (tmp_path / 'ok1').read_text() == '[1, 3, 5]'
+
+
+_CFG_SRC = """
+custom_imports = dict(imports=['model.BDE2VID'], allow_failed_imports=False)
+num_bins = 5
+base = 16
+buffer = [-2, -1, 0, 1, 2]
+losses = [dict(type='L1Loss', weight=1.0)]
+model = dict(
+    type='BDE2VID',
+    cpu_cache_length=100,
+    generator=dict(
+        type='BDE2VIDCrossscalePropogationV5',
+        num_bins=num_bins, basechannels=base, num_encoders=3, ks=5, num_res_blocks=2,
+        norm=None, recurrent_block_type='convlstm', useRC=True, skip_type='sum',
+        activation=dict(type='Sigmoid'), buffer_index=buffer, q_idx=len_half,
+        window_size=(7, 7), depths=[1, 2, 3], num_heads=2 * 4, drop_path_rate=0.2,
+        losses=losses, loss_inds=None))
+train_dataloader = dict(batch_size=2, dataset=dict(type='SomeDataset', root=data_root))
+"""
+
+
+def test_checkpoint_config_is_parsed_without_executing_it(tmp_path):
+    from bde2vid_amd.checkpoint import generator_config_from_cfg, parse_config_source, load_model
+    src = _CFG_SRC.replace('len_half', '2')
+    cfg = generator_config_from_cfg(src)
+    assert (cfg.basechannels, cfg.depths, cfg.num_heads, cfg.buffer_index, cfg.q_idx, cfg.activation) == \
+        (16, (1, 2, 3), 8, (-2, -1, 0, 1, 2), 2, 'Sigmoid')
+    env = parse_config_source(src)
+    assert env['model']['cpu_cache_length'] == 100 and 'train_dataloader' not in env   # unresolved names are skipped
+    with pytest.raises(ValueError):
+        generator_config_from_cfg("model = dict(type='E2VIDRecurrent', generator=dict())")
+    with pytest.raises(ValueError):
+        generator_config_from_cfg("import os\nmodel = __import__('os').system('true')")   # never executed
+    # a file in the reference's checkpoint format; loading needs the GPU, parsing does not
+    sd = formula_state_dict(cfg)
+    path = tmp_path / 'BDE2VID.pth'
+    torch.save({'state_dict': sd, 'meta': {'cfg': src}}, str(path))
+    if torch.cuda.is_available():
+        m = load_model(str(path))
+        assert m.cfg.depths == (1, 2, 3)
+    else:
+        with pytest.raises(RuntimeError):
+            load_model(str(path))
