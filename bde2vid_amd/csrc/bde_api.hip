@@ -334,6 +334,8 @@ struct bde_model {
     hipEvent_t join_ev = nullptr;
     int overlap = 0;              // measured neutral-to-negative at config A (contention slows the chain): off
     int overlap_chunk = 4;        // frames handed to the side stream per launch set
+    int debug_skip = 0;           // diagnostic what-if timing only (results are wrong): bit0 attention level 0, bit1 attention levels >= 1,
+                                  // bit2 recurrent steps, bit3 decoder, bit4 encoder + gate convs
     int tok_debug = 0;
     unsigned long long* tok_stamps = nullptr;
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
@@ -748,13 +750,13 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     Workspace& ws = m->W();
     const int C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
-    if (!enc_done) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
+    if (!enc_done && !(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
     // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
     const PackedLayer& pl = m->lstm[l];
     float* hs = ws.hseq[l];
     const long dstride = TB * C * hw;          // direction stride inside hseq
     const long fs = (long)B * C * hw;          // one time step (B frames)
-    for (int st = 0; st < T; ++st) {
+    for (int st = 0; st < T && !(m->debug_skip & 4); ++st) {
         const int tf = st, tb = T - 1 - st;
         ConvArgs a;
         memset(&a, 0, sizeof a);
@@ -1087,7 +1089,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         enc_done = false;
         const long n = TB * C * h * w;
         BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s));   // V5.py:137-147
-        if (c.depths[l] > 0) {
+        if (c.depths[l] > 0 && !(m->debug_skip & (l == 0 ? 1 : 2))) {
             static const char* names[BDE_MAX_LEVELS] = {"attn0", "attn1", "attn2", "attn3", "attn4", "attn5", "attn6", "attn7"};
             ProfScope ps(m, names[l], s);
             SideCtx sc{l, T, B, H, W, s, m->side, l == L - 1, m->overlap_chunk};
@@ -1115,7 +1117,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         }
         target = ws.merged[l];
     }
-    if (!decoded) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s));
+    if (!decoded && !(m->debug_skip & 8)) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s));
     return BDE_OK;
 }
 
@@ -1287,6 +1289,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_debug") { m->tok_debug = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap") { m->overlap = (int)value; return BDE_OK; }
+    if (std::string(key) == "debug_skip") { m->debug_skip = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap_chunk") { m->overlap_chunk = std::max<int>(1, (int)value); return BDE_OK; }
     return fail(BDE_ERR_ARG, "unknown tuning key '%s'", key);
 }
@@ -1310,7 +1313,7 @@ int bde_debug_occupancy(const char* kernel) {
     std::string k(kernel ? kernel : "");
     hipError_t e = hipErrorInvalidValue;
     if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 1>, 256, 0);
-    else if (k == "lstm16_1_64_hb2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 2>, 256, 0);
+    else if (k == "lstm16_1_128_s2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 128, 2>, 256, 0);
     else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32, 1>, 256, 0);
     else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64));
     else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, conv_maxi(3)>, 256, 42 * 1024);

@@ -64,7 +64,6 @@ struct ConvArgs {
     float* cstate;       // [G][N][Ch][HW]    cell state, updated in place
     long gx_gs, gx_ns, c_gs, c_ns;
     int first;           // 1: h_prev == 0 -> skip the contraction entirely
-    unsigned long long* dbg_stamps;   // diagnostics only (lstm16.h): s_memtime per stage phase
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU

@@ -22,30 +22,51 @@ namespace bde {
 
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
+// sigmoid / tanh on the hardware 2^x and reciprocal (1 ulp each): absolute error ~2e-7, against ~25 and
+// ~35 instructions for the libm forms -- the pointwise tail of a step is 5 of these per (channel, pixel)
+// and every wave of a launch reaches it at the same time, so it is not hidden behind other waves' MFMAs
+__device__ __forceinline__ float sigmoid_fast(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
+__device__ __forceinline__ float tanh_fast(float v) {
+    return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -2.8853900817779268f)) - 1.f;
+}
+
 constexpr int L16_CK = 8;                        // channels per stage
 constexpr int L16_AFL = 9 * 2 * 4 * 64;          // floats of one stage's weight fragments (18 KiB)
-// plane stride of the halo tile, padded to 16 (mod 32) floats
-constexpr int l16_ps(int rows, int pxw) { return ((rows + 2) * (pxw + 2) + 15) / 32 * 32 + 16; }
+// LDS row stride of the halo tile [channel][tile row][IWP]: >= PXW + 2 and chosen so that the plane
+// stride (ROWS + 2) * IWP is 16 (mod 32) floats -- the four channel rows of a B fragment then fall on
+// disjoint banks
+constexpr int l16_iwp(int rows, int pxw) {
+    int v = pxw + 2;
+    while (((rows + 2) * v) % 32 != 16) ++v;
+    return v;
+}
 
-// A workgroup covers ROWS image rows x PXW pixels, one 16-pixel segment per wave (ROWS*PXW/16 waves:
-// 4 or 8), and HB blocks of 16 hidden channels.  <1,64> for wide maps, <2,32> / <4,16> for narrow ones
-// so that all waves have pixels.  In-kernel stamps (level 0 of config A): ~80 % MFMA duty while four
-// workgroups share a CU, 54 % for a workgroup alone; the launch is 1472 workgroups on 1024 resident
-// slots, and the second, thinly populated round costs about a quarter of it.  HB = 2 (half the waves,
-// one round) was built to fix that but needs 176 registers -> 2 waves/SIMD, and measured slower.
+// A workgroup covers ROWS image rows x PXW pixels of 16 hidden channels; a wave owns SEG 16-pixel
+// segments of one row (ROWS*PXW/(16*SEG) waves = 4).  <1,64,1> / <2,32,1> / <4,16,1> keep every wave
+// busy on narrow maps; <1,128,2> halves the waves of a wide level: level 0 of config A is then 736
+// workgroups that are all resident at once (the one-segment shape needs 1472 on 1024 slots, and its
+// thinly populated second round cost about a quarter of the launch), each weight fragment read from
+// LDS feeds two MFMAs, and the weights are staged once per 128 pixels instead of once per 64.
+// The halo tile is staged row-wise: a pass of all threads copies NT/PXW tile rows of PXW floats
+// (coalesced, LDS address affine in the pass number), one more pass the two right-hand halo columns.
 // Uses the ConvArgs fields of EPI_LSTM (in = h_prev, out = h, gx, cstate, first, strides).
-template <int ROWS, int PXW, int HB>
-__global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvArgs a) {
-    constexpr int NT = ROWS * PXW * 4;               // threads per workgroup (64 per 16-pixel segment)
-    constexpr int AFL4 = HB * L16_AFL / 4;           // float4 of one stage's weight fragments
-    constexpr int L16_AK4 = (AFL4 + NT - 1) / NT;    // 16-byte weight loads per thread and stage
-    constexpr int L16_IW = PXW + 2;
-    constexpr int L16_R = ROWS + 2;
-    constexpr int L16_PS = l16_ps(ROWS, PXW);
-    constexpr int L16_BK = (L16_CK * L16_R * L16_IW + NT - 1) / NT;
-    constexpr int XT = PXW / 16;                     // waves along x
-    __shared__ __align__(16) float ldsA[HB * L16_AFL];
-    __shared__ __align__(16) float ldsB[L16_CK * L16_PS];
+template <int ROWS, int PXW, int SEG>
+__global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_per_eu(SEG == 1 ? 4 : 3, 8))) void lstm16_step_kernel(const ConvArgs a) {
+    constexpr int NT = ROWS * PXW * 4 / SEG;         // threads per workgroup (64 per wave)
+    constexpr int AFL4 = L16_AFL / 4;                // float4 of one stage's weight fragments
+    constexpr int AK4 = (AFL4 + NT - 1) / NT;        // 16-byte weight loads per thread and stage
+    constexpr int R = ROWS + 2;
+    constexpr int IWP = l16_iwp(ROWS, PXW);
+    constexpr int PLS = R * IWP;                     // plane (channel) stride in LDS
+    constexpr int NR = L16_CK * R;                   // tile rows per stage
+    constexpr int RPP = NT / PXW;                    // tile rows per staging pass
+    constexpr int NPASS = NR / RPP;
+    static_assert(NR % RPP == 0 && NT % PXW == 0 && 2 * NR <= NT, "halo staging shape");
+    constexpr int XT = PXW / (16 * SEG);             // waves along x
+    __shared__ __align__(16) float ldsA[L16_AFL];
+    __shared__ __align__(16) float ldsB[L16_CK * PLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.z;
     const int g = z / a.N, n = z - g * a.N;
@@ -53,141 +74,161 @@ __global__ __launch_bounds__(ROWS * PXW * 4) void lstm16_step_kernel(const ConvA
     const int tiles_x = (W + PXW - 1) / PXW;
     const int ty = blockIdx.x / tiles_x;
     const int y0 = ty * ROWS, x0 = (blockIdx.x - ty * tiles_x) * PXW;
-    const int hb0 = blockIdx.y * HB;                         // first hidden16 block of this workgroup
-    const int nhb = (Ch + 15) / 16;
-    const int wrow = wave / XT, wx = wave - wrow * XT;       // this wave's row and 16-pixel segment
-    const int pxl = wx * 16 + (lane & 15);                   // x of this lane inside the tile
+    const int hb = blockIdx.y;                               // hidden16 block of this workgroup
+    const int wrow = wave / XT, wx = wave - wrow * XT;       // this wave's row and first 16-pixel segment
+    const int pxl = wx * 16 * SEG + (lane & 15);             // x of this lane (segment 0) inside the tile
     const int y = y0 + wrow;
-    const bool pvalid = (x0 + pxl) < W && y < H;
-    const bool wave_active = (x0 + wx * 16) < W && y < H;
+    const bool wave_active = (x0 + wx * 16 * SEG) < W && y < H;
 
-    f32x4_ acc[HB][4];
+    f32x4_ acc[SEG][4];
 #pragma unroll
-    for (int h = 0; h < HB; ++h)
+    for (int sg = 0; sg < SEG; ++sg)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[h][q] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) acc[sg][q] = f32x4_{0.f, 0.f, 0.f, 0.f};
 
+    // gx / c_prev of this lane's (pixel, 4 hidden channels) x SEG, fetched during the last stage
+    float gv[SEG][4][4], cprev[SEG][4];
+    const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
+    float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
+    auto epi_load = [&]() {
+#pragma unroll
+        for (int sg = 0; sg < SEG; ++sg) {
+            const unsigned p = (unsigned)(min(y, H - 1) * W + min(x0 + pxl + sg * 16, W - 1));   // clamped: in bounds
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned hc = (unsigned)min(hb * 16 + (lane >> 4) * 4 + r, Ch - 1);
+                const unsigned o = hc * (unsigned)HW + p;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gv[sg][q][r] = gxb[(unsigned)(q * Ch) * (unsigned)HW + o];
+                cprev[sg][r] = a.first ? 0.f : cst[o];
+            }
+        }
+    };
+
+    if (a.first) epi_load();
     if (!a.first) {
         const float* inb = a.in + g * a.in_gs + n * a.in_ns;
-        const float* wgrp = a.wpk + g * a.w_gs;
-        // fixed staging slots of this thread for the halo tile: element e = (ci, r, col)
-        int boffs[L16_BK];
-        unsigned bsrc[L16_BK];
+        const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + g * a.w_gs + (long)hb * a.nchunks * L16_AFL);
+        // halo staging slots of this thread
+        const int sub = tid / PXW, col = tid - sub * PXW;
+        const int ixm = x0 - 1 + col;
+        const bool colok = ixm >= 0 && ixm < W;
+        const int xrow = tid >> 1, ixx = x0 - 1 + PXW + (tid & 1);     // extra pass: right-hand halo columns
+        const bool xok = tid < 2 * NR && ixx < W;
+        // source offsets of this thread's halo slots inside a stage (the stage only moves the base pointer)
+        unsigned bsrc[NPASS + 1];
         unsigned bmask = 0;
 #pragma unroll
-        for (int k = 0; k < L16_BK; ++k) {
-            const int e = tid + k * NT;
-            const int ci = e / (L16_R * L16_IW), rem = e - ci * (L16_R * L16_IW);
-            const int r = rem / L16_IW, col = rem - r * L16_IW;
-            const int iy = y0 - 1 + r, ix = x0 - 1 + col;
-            const bool item = e < L16_CK * L16_R * L16_IW;
-            boffs[k] = item ? ci * L16_PS + r * L16_IW + col : -1;
-            const bool ok = item && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        for (int k = 0; k <= NPASS; ++k) {
+            const int row = k < NPASS ? k * RPP + sub : xrow;
+            const int ci = row / R, r = row - ci * R;
+            const int iy = y0 - 1 + r;
+            const bool ok = (k < NPASS ? colok : xok) && iy >= 0 && iy < H;
             if (ok) bmask |= 1u << k;
-            bsrc[k] = ok ? (unsigned)(ci * HW + iy * W + ix) : 0u;
+            bsrc[k] = ok ? (unsigned)(ci * HW + iy * W + (k < NPASS ? ixm : ixx)) : 0u;
         }
-        // weight staging slot k of this thread: float4 index i4 inside the HB stacked fragment blocks
-        float4 aw[L16_AK4];
-        float bw[L16_BK];
+        float4 aw[AK4];
+        float bw[NPASS + 1];
         auto stage_load = [&](int st) {
             // 16-byte loads (a stage of dword loads queued for thousands of cycles on the VMEM path)
 #pragma unroll
-            for (int k = 0; k < L16_AK4; ++k) {
+            for (int k = 0; k < AK4; ++k) {
                 const int i4 = tid + k * NT;
-                const int h = i4 / (L16_AFL / 4), r4 = i4 - h * (L16_AFL / 4);
-                const int hbc = min(hb0 + h, nhb - 1);       // (a padded hidden block re-reads the last one)
-                const float4* wsrc = reinterpret_cast<const float4*>(wgrp + ((long)hbc * a.nchunks + st) * L16_AFL);
-                aw[k] = (i4 < AFL4) ? wsrc[r4] : float4{0.f, 0.f, 0.f, 0.f};
+                aw[k] = (i4 < AFL4) ? wsrc[(long)st * AFL4 + i4] : float4{0.f, 0.f, 0.f, 0.f};
             }
             const float* cb = inb + (long)st * L16_CK * HW;
             // exec-masked loads: fastest of the three zero-padding forms tried (select at load time,
             // select at LDS-store time, masked load)
 #pragma unroll
-            for (int k = 0; k < L16_BK; ++k) bw[k] = ((bmask >> k) & 1u) ? cb[bsrc[k]] : 0.f;
+            for (int k = 0; k <= NPASS; ++k) bw[k] = ((bmask >> k) & 1u) ? cb[bsrc[k]] : 0.f;
         };
-        const int bofl = (lane >> 4) * L16_PS + wrow * L16_IW + pxl;   // tap (0,0), k4 = 0
+        const int bofl = (lane >> 4) * PLS + wrow * IWP + pxl;   // tap (0,0), k4 = 0, segment 0
         const int nst = a.nchunks;
-        stage_load(0);
-        for (int st = 0; st < nst; ++st) {
+        auto stage_store = [&]() {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < L16_AK4; ++k) {
+            for (int k = 0; k < AK4; ++k) {
                 const int i4 = tid + k * NT;
                 if (i4 < AFL4) reinterpret_cast<float4*>(ldsA)[i4] = aw[k];
             }
 #pragma unroll
-            for (int k = 0; k < L16_BK; ++k)
-                if (boffs[k] >= 0) ldsB[boffs[k]] = bw[k];
+            for (int k = 0; k < NPASS; ++k) ldsB[(k * RPP + sub) * IWP + col] = bw[k];
+            if (tid < 2 * NR) ldsB[xrow * IWP + PXW + (tid & 1)] = bw[NPASS];
             __syncthreads();
-            if (st + 1 < nst) stage_load(st + 1);
-            if (!wave_active) continue;                       // this wave's 16 pixels lie outside the map
+        };
+        auto stage_mfma = [&]() {
+            // Fragment reads run one tap ahead of the MFMAs (two register sets): a wave alone on its SIMD
+            // otherwise idles the matrix pipe for an LDS round trip after every tap, and the waves of a
+            // launch move through their stages too much in step to cover that for each other.
+            float bq[2][2][SEG], aq[2][2][4];
+            auto frag_read = [&](int tap, int buf) {
+                const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int k4 = 0; k4 < 2; ++k4) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    // all LDS reads of a tap first, then its MFMAs (hipcc otherwise emits
-                    // read -> lgkmcnt(0) -> MFMA chains and exposes the LDS latency per k-step)
-                    float bq[2], aq[HB][2][4];
+                    for (int sg = 0; sg < SEG; ++sg) bq[buf][k4][sg] = ldsB[bofl + k4 * 4 * PLS + ky * IWP + kx + sg * 16];
+                    const float* ap = ldsA + ((tap * 2 + k4) * 4) * 64 + lane;
 #pragma unroll
-                    for (int k4 = 0; k4 < 2; ++k4) {
-                        bq[k4] = ldsB[bofl + k4 * 4 * L16_PS + ky * L16_IW + kx];
-#pragma unroll
-                        for (int h = 0; h < HB; ++h) {
-                            const float* ap = ldsA + h * L16_AFL + (((ky * 3 + kx) * 2 + k4) * 4) * 64 + lane;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) aq[h][k4][q] = ap[q * 64];
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k4 = 0; k4 < 2; ++k4)
-#pragma unroll
-                        for (int h = 0; h < HB; ++h)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                acc[h][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[h][k4][q], bq[k4], acc[h][q], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) aq[buf][k4][q] = ap[q * 64];
                 }
+            };
+            frag_read(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int buf = tap & 1;
+                if (tap + 1 < 9) frag_read(tap + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+                    for (int sg = 0; sg < SEG; ++sg)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[sg][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[buf][k4][q], bq[buf][k4][sg], acc[sg][q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        stage_load(0);
+        for (int st = 0; st + 1 < nst; ++st) {
+            stage_store();
+            stage_load(st + 1);
+            if (wave_active) stage_mfma();                    // (else this wave's pixels lie outside the map)
         }
+        // last stage, peeled: the staging registers are free, the pointwise operands take their place
+        stage_store();
+        epi_load();
+        if (wave_active) stage_mfma();
     }
 
     // ---- pointwise (submodules.py:320-332); gate order i, f, o, g ------------------------------
-    if (!pvalid) return;
-    const long p = (long)y * W + x0 + pxl;
+    if (y >= H) return;
     float* hout = a.out + g * a.out_gs + n * a.out_ns;
-    float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
-    const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
 #pragma unroll
-    for (int h = 0; h < HB; ++h) {
-        float gv[4][4], cprev[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int hc = min((hb0 + h) * 16 + (lane >> 4) * 4 + r, Ch - 1);
-            const long o = (long)hc * HW + p;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gv[q][r] = gxb[(long)q * Ch * HW + o];
-            cprev[r] = a.first ? 0.f : cst[o];
-        }
+    for (int sg = 0; sg < SEG; ++sg) {
+        const int x = x0 + pxl + sg * 16;
+        if (x >= W) continue;
+        const long p = (long)y * W + x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int hc = (hb0 + h) * 16 + (lane >> 4) * 4 + r;
+            const int hc = hb * 16 + (lane >> 4) * 4 + r;
             if (hc >= Ch) continue;
             const long o = (long)hc * HW + p;
-            const float gi = acc[h][0][r] + gv[0][r], gf = acc[h][1][r] + gv[1][r];
-            const float go = acc[h][2][r] + gv[2][r], gg = acc[h][3][r] + gv[3][r];
-            const float c = sigmoidf_(gf) * cprev[r] + sigmoidf_(gi) * tanhf(gg);
+            const float gi = acc[sg][0][r] + gv[sg][0][r], gf = acc[sg][1][r] + gv[sg][1][r];
+            const float go = acc[sg][2][r] + gv[sg][2][r], gg = acc[sg][3][r] + gv[sg][3][r];
+            const float c = sigmoid_fast(gf) * cprev[sg][r] + sigmoid_fast(gi) * tanh_fast(gg);
             cst[o] = c;
-            hout[o] = sigmoidf_(go) * tanhf(c);
+            hout[o] = sigmoid_fast(go) * tanh_fast(c);
         }
     }
 }
 
-inline int& lstm16_shape_ref() { static int v = 0; return v; }    // tuning: hb*100000 + rows*1000 + pxw, 0 = auto
+inline int& lstm16_shape_ref() { static int v = 0; return v; }    // tuning: seg*100000 + rows*1000 + pxw, 0 = auto
 
-template <int ROWS, int PXW, int HB>
+template <int ROWS, int PXW, int SEG>
 static int lstm16_launch_t(const ConvArgs& a, hipStream_t stream) {
     const int Ch = a.Cout / 4;
-    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, 16 * HB), 2 * a.N);
-    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW, HB>), grid, dim3(ROWS * PXW * 4), 0, stream, a);
+    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, 16), 2 * a.N);
+    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW, SEG>), grid, dim3(ROWS * PXW * 4 / SEG), 0, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
@@ -200,23 +241,20 @@ static int lstm16_launch(const ConvArgs& a, hipStream_t stream) {
         return segs / ((double)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * (rows * pxw / 16));
     };
     const int shapes[3][2] = {{1, 64}, {2, 32}, {4, 16}};
-    int rows = 1, pxw = 64;
+    int rows = 1, pxw = 64, seg = 1;
     double bf = -1;
     for (auto& sh : shapes) { const double f = fill(sh[0], sh[1]); if (f > bf + 0.02) { bf = f; rows = sh[0]; pxw = sh[1]; } }
-    // one hidden16 block per workgroup gives 4 waves/SIMD of residency (1024 workgroups on the chip);
-    // above that, two blocks per workgroup (3 waves/SIMD, 768 workgroups) keep the launch in one round
+    // more one-segment workgroups than the chip holds at once (4 per CU): two segments per wave
     const long wg1 = (long)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * cdiv(a.Cout / 4, 16) * 2 * a.N;
-    (void)wg1;
-    int hb = 1;   // measured: HB = 2 needs 176 registers (2 waves/SIMD) and loses 6-12 % at every level of config A
-    if (const int f = lstm16_shape_ref()) { hb = f / 100000; rows = (f / 1000) % 100; pxw = f % 1000; }
-#define BDE_L16(R_, P_)                                                                  \
-    if (rows == R_ && pxw == P_)                                                         \
-        return hb == 2 ? lstm16_launch_t<R_, P_, 2>(a, stream) : lstm16_launch_t<R_, P_, 1>(a, stream);
-    BDE_L16(1, 64)
-    BDE_L16(2, 32)
-    BDE_L16(4, 16)
+    if (wg1 > 1024 && fill(1, 128) >= bf - 0.08) { rows = 1; pxw = 128; seg = 2; }
+    if (const int f = lstm16_shape_ref()) { seg = f / 100000; rows = (f / 1000) % 100; pxw = f % 1000; }
+#define BDE_L16(R_, P_, S_) if (rows == R_ && pxw == P_ && seg == S_) return lstm16_launch_t<R_, P_, S_>(a, stream);
+    BDE_L16(1, 64, 1)
+    BDE_L16(2, 32, 1)
+    BDE_L16(4, 16, 1)
+    BDE_L16(1, 128, 2)
 #undef BDE_L16
-    return fail(BDE_ERR_ARG, "recurrent step: tile shape %dx%d not built", rows, pxw);
+    return fail(BDE_ERR_ARG, "recurrent step: tile shape %dx%d (x%d segments) not built", rows, pxw, seg);
 }
 
 }  // namespace bde
