@@ -21,6 +21,7 @@
 #include "pw_gemm.h"
 #include "token_fused.h"
 #include "lstm16.h"
+#include "winblock.h"
 #include "conv_vec.h"
 #include "voxel.h"
 
@@ -268,6 +269,7 @@ struct AttnBlock {
     long proj16 = -1, fc1_16 = -1, fc2_16 = -1, qkv16 = -1;   // 16x16x4 packings for token_fused.h
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
+    long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
 };
 struct AttnLevel {
     int depth = 0, C = 0;
@@ -281,7 +283,7 @@ struct Workspace {
     float* ev = nullptr;
     float* head = nullptr;
     float* out = nullptr;
-    std::vector<float*> xenc, gx, hseq, cst, merged, kvun, kvref, dec, qkv0;
+    std::vector<float*> xenc, gx, hseq, cst, merged, mergedT, kvun, kvref, dec, qkv0;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
@@ -338,6 +340,7 @@ struct bde_model {
                                   // bit2 recurrent steps, bit3 decoder, bit4 encoder + gate convs
     int tok_debug = 0;
     unsigned long long* tok_stamps = nullptr;
+    int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -523,6 +526,33 @@ static int build_packed(bde_model* m) {
                     for (int h = 0; h < heads; ++h) bt[((long)h * N + n) * 49 + mq] = LOG2E * tbl[(long)idx * heads + h];
                 }
             }
+            if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
+                // winblock.h: keys reordered query frame first, score tile (query tile i, key tile j) in the
+                // C/D register order of the 16x16x4 MFMA: [head][i][j][r][lane], key = 16j + 4(lane>>4) + r
+                ab.biasF_off = ar.alloc((long)heads * 4 * WB_NT * 256);
+                float* bfp = ar.host.data() + ab.biasF_off;
+                for (int h = 0; h < heads; ++h)
+                    for (int qi = 0; qi < 4; ++qi)
+                        for (int j = 0; j < WB_NT; ++j)
+                            for (int r = 0; r < 4; ++r)
+                                for (int ln = 0; ln < 64; ++ln) {
+                                    const int u = 16 * j + 4 * (ln >> 4) + r;
+                                    const int mq = std::min(16 * qi + (ln & 15), 48);
+                                    float v = -1e30f;
+                                    if (u < N) {
+                                        int n;                       // key row of the reference order (slot-major)
+                                        if (u < 49) n = c.q_idx * 49 + u;
+                                        else {
+                                            const int w = u - 49;
+                                            int d = w / 49;              // index among the non-query slots
+                                            if (d >= c.q_idx) ++d;
+                                            n = d * 49 + w % 49;
+                                        }
+                                        v = bt[((long)h * N + n) * 49 + mq];
+                                    }
+                                    bfp[((((long)h * 4 + qi) * WB_NT + j) * 4 + r) * 64 + ln] = v;
+                                }
+            }
             DenseLayer proj;
             proj.rows = C; proj.Cin = C; proj.KS = 1;
             proj.w.assign(wp, wp + (size_t)C * C);
@@ -676,7 +706,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     BDE_TRY(ws_alloc(ws, &ws.head, TB * c.basechannels * H * W));
     BDE_TRY(ws_alloc(ws, &ws.out, TB * H * W));
     ws.xenc.assign(L, nullptr); ws.gx.assign(L, nullptr); ws.hseq.assign(L, nullptr); ws.cst.assign(L, nullptr);
-    ws.merged.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
+    ws.merged.assign(L, nullptr); ws.mergedT.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
     long max_attn = 0;
     for (int l = 0; l < L; ++l) {
         const long C = m->cout(l), hw = (long)(H >> (l + 1)) * (W >> (l + 1));
@@ -689,6 +719,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
             BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
             BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
             BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
+            BDE_TRY(ws_alloc(ws, &ws.mergedT[l], TB * C * hw));   // token-major twin of merged (winblock.h)
             max_attn = std::max(max_attn, (long)B * C * hw);
         }
         const int j = L - 1 - l;   // decoder j writes the map of level (L-1-j)'s input resolution
@@ -888,6 +919,59 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
     return BDE_OK;
 }
 
+static bool winblock_ok(const bde_model* m, int l) {
+    const AttnLevel& al = m->attn[l];
+    return m->winblock && al.depth > 0 && al.blocks[0].biasF_off >= 0 && al.blocks[0].qkv16 >= 0;
+}
+
+// One frame through the blocks of a level with winblock.h.  Everything is token-major [B][HW][C]:
+//   frames[d]: frame of slot d (nullptr = zero frame), frames[q_idx] = the query frame
+//   addres   : added to the result (merged[t], V5.py:166) or nullptr
+//   out_tok  : result, token-major;  out_nchw: the same result as [B][C][HW] planes (may be nullptr)
+static int run_attention_frame_win(bde_model* m, int l, const float* const* frames, const float* addres, float* out_tok,
+                                   float* out_nchw, int B, int H, int W, int blk0, int nblk, hipStream_t s) {
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->W();
+    const AttnLevel& al = m->attn[l];
+    const int C = al.C, D = c.frame_num;
+    const long HW = (long)H * W;
+    const int ph = (7 - H % 7) % 7, pw = (7 - W % 7) % 7;   // DTransformer.py:260-263
+    const float* x = frames[c.q_idx];
+    for (int i = blk0; i < blk0 + nblk; ++i) {
+        const AttnBlock& ab = al.blocks[i];
+        const bool last = (i == blk0 + nblk - 1);
+        float* dst = last ? out_tok : (x == ws.xa ? ws.xb : ws.xa);
+        WinArgs a;
+        memset(&a, 0, sizeof a);
+        a.slot[0] = x;
+        a.slot_bs[0] = C * HW;
+        int k = 1;
+        for (int d = 0; d < D; ++d) {
+            if (d == c.q_idx) continue;
+            a.slot[k] = frames[d];
+            a.slot_bs[k] = C * HW;
+            ++k;
+        }
+        a.nslots = D;
+        a.addres = last ? addres : nullptr;
+        a.addres_bs = C * HW;
+        a.out = dst;
+        a.out_nchw = last ? out_nchw : nullptr;
+        a.out_bs = C * HW;
+        a.wqkv = m->P(ab.qkv16);   a.bqkv = m->P(ab.qkv.b_off);  a.sqkv = m->P(ab.qkv.s_off);
+        a.wproj = m->P(ab.proj16); a.bproj = m->P(ab.proj.b_off);
+        a.wfc1 = m->P(ab.fc1_16);  a.bfc1 = m->P(ab.fc1.b_off);  a.sfc1 = m->P(ab.fc1.s_off);
+        a.wfc2 = m->P(ab.fc2_16);  a.bfc2 = m->P(ab.fc2.b_off);
+        a.biasF = m->P(ab.biasF_off);
+        a.stamps = m->tok_stamps;
+        a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw; a.pt = ph / 2; a.pl = pw / 2;
+        a.dilated = (i % 2) == 1 ? 1 : 0;                    // DTransformer.py:362
+        BDE_TRY(winblock_launch(a, B, s));
+        x = dst;
+    }
+    return BDE_OK;
+}
+
 typedef int (*FrameDoneFn)(bde_model* m, int t, void* ctx);
 static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, hipStream_t s,
                                FrameDoneFn on_frame = nullptr, void* ctx = nullptr) {
@@ -897,6 +981,23 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
     const int C = al.C, D = c.frame_num;
     const long HW = (long)H * W, fs = (long)B * C * HW;
     const long kvfs = (long)B * al.depth * 2 * C * HW;
+    if (winblock_ok(m, l)) {
+        // one launch per block; the K|V of the neighbour frames are recomputed inside from the frames
+        // themselves (refined in place for f < t, V5.py:166-169), so nothing else is staged per level
+        BDE_TRY(nchw_to_tok(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s));
+        for (int t = 0; t < T; ++t) {
+            const float* frames[BDE_MAX_FRAMES];
+            for (int d = 0; d < D; ++d) {
+                const int f = t + c.buffer_index[d];
+                frames[d] = (f < 0 || f >= T) ? nullptr : ws.mergedT[l] + (long)f * fs;
+            }
+            float* mt = ws.mergedT[l] + (long)t * fs;
+            frames[c.q_idx] = mt;
+            BDE_TRY(run_attention_frame_win(m, l, frames, mt, mt, ws.merged[l] + (long)t * fs, B, H, W, 0, al.depth, s));
+            if (on_frame) BDE_TRY(on_frame(m, t, ctx));
+        }
+        return BDE_OK;
+    }
     bool need_un = false, need_ref = false;
     for (int d = 0; d < D; ++d) {
         if (d == c.q_idx) continue;
@@ -1281,6 +1382,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     }
     for (auto& w : m->wslots)
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
+    if (std::string(key) == "winblock") { m->winblock = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { pw_batched_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
@@ -1469,6 +1571,17 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
     const int D = c.frame_num;
     BDE_TRY(ensure_workspace(m, D, B, H << (level + 1), W << (level + 1)));
     const long HW = (long)H * W;
+    if (winblock_ok(m, level)) {
+        const float* frames[BDE_MAX_FRAMES];
+        for (int d = 0; d < D; ++d) {
+            frames[d] = nullptr;
+            if (bufs[d] == nullptr) continue;
+            float* tq = m->W().mergedT[level] + (long)d * B * al.C * HW;
+            BDE_TRY(nchw_to_tok(bufs[d], tq, B, al.C, (int)HW, s));
+            frames[d] = tq;
+        }
+        return run_attention_frame_win(m, level, frames, nullptr, m->W().qkv, out, B, H, W, first_block, nblocks, s);
+    }
     const long kvfs = (long)B * al.depth * 2 * al.C * HW;
     const float* kvslot[BDE_MAX_FRAMES];
     for (int d = 0; d < D; ++d) {

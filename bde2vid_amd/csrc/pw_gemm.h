@@ -243,7 +243,6 @@ static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
     const long px_tiles = cdiv(a.Wo, 32);
     const long frames = (long)G * a.N;
     const int kpairs = a.Cin / 2;
-    const long t2 = px_tiles * cdiv(a.Cout, 64) * frames;     // wave tasks with MT = 2
     const long t1 = px_tiles * cdiv(a.Cout, 32) * frames;     // wave tasks with MT = 1
     // T-batched launches are bound by their output stores (K is only 64..256): the lean one-tile-per-
     // wave variant (4 waves/SIMD) measured ahead of the register-heavy 2x2 and 2x1 ones
