@@ -1,0 +1,98 @@
+"""GPU parity of the one-launch attention block (csrc/winblock.h) at the canonical 64-channel / 16-head
+level 0, against the CPU oracle (oracle/bde2vid_oracle.py, itself pinned to the reference by the golden
+vectors) and against the split path (attention core + fused token kernel) of the same library.
+
+Shapes pick out the kernel's cases: padding on both sides of the window grid, maps of a single window,
+dilated blocks whose uncovered pixels ride in the spare token columns (large maps) or need the extra
+workgroups (few windows: more than 15 uncovered pixels per window), zero frames at the sequence ends,
+batch > 1.  fp32; tolerance as in test_gpu_blocks.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import maxabs, dense_like
+from bde2vid_amd import canonical
+from bde2vid_amd.weights import formula_state_dict, relative_position_index
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def model_a():
+    from bde2vid_amd.model import build_model
+    cfg = canonical()
+    sd = formula_state_dict(cfg)
+    return cfg, sd, build_model(cfg, sd, 'cuda:0')
+
+
+def oracle_blocks(cfg, sd, bufs, first, n):
+    from oracle import bde2vid_oracle as O
+    rel = torch.from_numpy(relative_position_index(cfg.frame_num, 7, 7))
+    keys = [b if b is not None else torch.zeros_like(bufs[cfg.q_idx]) for b in bufs]
+    x = keys[cfg.q_idx]
+    for i in range(first, first + n):
+        keys[cfg.q_idx] = x
+        x = O.swin_block(torch.stack(keys, 0), sd, f'{O.P}feat_attns.0.blocks.{i}.', cfg.num_heads, cfg.q_idx, i % 2 == 1, 7, rel)
+    return x
+
+
+SHAPES = [
+    (1, 64, 17, 23),     # pads 4 / 5, 12 windows: 10 uncovered pixels per window in dilated blocks
+    (1, 64, 7, 7),       # one window, no padding: 33 uncovered pixels -> extra workgroups
+    (2, 64, 14, 14),     # 4 windows, batch 2: 19 per window -> extra workgroups
+    (1, 64, 30, 41),     # pads 5 / 1
+    (1, 64, 46, 60),     # level-0 map of a 92 x 120 input
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_single_blocks_vs_oracle(model_a, shape):
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    bufs = [torch.from_numpy(dense_like(shape, 300 + d)) for d in range(3)]
+    dev = [b.cuda() for b in bufs]
+    for blk in (0, 1):                                   # plain, dilated
+        ref = oracle_blocks(cfg, sd, bufs, blk, 1)
+        assert maxabs(ops.dframe_attention(m, 0, dev, blk, 1), ref) <= TOL, f'block {blk}'
+
+
+@pytest.mark.parametrize('shape', SHAPES[:4])
+def test_all_blocks_vs_oracle_and_split_path(model_a, shape):
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    bufs = [torch.from_numpy(dense_like(shape, 320 + d)) for d in range(3)]
+    dev = [b.cuda() for b in bufs]
+    ref = oracle_blocks(cfg, sd, bufs, 0, cfg.depths[0])
+    y = ops.dframe_attention(m, 0, dev)
+    assert maxabs(y, ref) <= TOL
+    m.set_tuning('winblock', 0)
+    try:
+        y_split = ops.dframe_attention(m, 0, dev)
+    finally:
+        m.set_tuning('winblock', 1)
+    assert maxabs(y, y_split.cpu()) <= TOL
+
+
+def test_zero_frames(model_a):
+    """Out-of-range temporal slots are all-zero frames (V5.py:152-161): their tokens are LayerNorm(0) = beta."""
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    q = torch.from_numpy(dense_like((1, 64, 15, 16), 341))
+    nxt = torch.from_numpy(dense_like((1, 64, 15, 16), 342))
+    for bufs in ([None, q, nxt], [nxt, q, None], [None, q, None]):
+        ref = oracle_blocks(cfg, sd, bufs, 0, 2)
+        y = ops.dframe_attention(m, 0, [None if b is None else b.cuda() for b in bufs], 0, 2)
+        assert maxabs(y, ref) <= TOL
+
+
+def test_inputs_untouched_and_deterministic(model_a):
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    dev = [torch.from_numpy(dense_like((1, 64, 21, 28), 360 + d)).cuda() for d in range(3)]
+    keep = [d.clone() for d in dev]
+    y0 = ops.dframe_attention(m, 0, dev)
+    y1 = ops.dframe_attention(m, 0, dev)
+    assert torch.equal(y0, y1)
+    for a, b in zip(dev, keep):
+        assert torch.equal(a, b)
