@@ -22,6 +22,7 @@
 #include "token_fused.h"
 #include "lstm16.h"
 #include "winblock.h"
+#include "attn_mfma.h"
 #include "conv_vec.h"
 #include "voxel.h"
 
@@ -878,7 +879,8 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
         a.out_bs = C * HW;
         a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
         a.pt = pt; a.pl = plft; a.nWw = Wp / 7; a.dilated = dil ? 1 : 0;
-        BDE_TRY(attn_launch(a, B, s));
+        if (C / c.num_heads == 16 && D * ATT_TOK <= 160 && attn_mfma_ref()) BDE_TRY(attn_mfma16_launch(a, B, s));
+        else BDE_TRY(attn_launch(a, B, s));
         float* dst = last ? out : (x == ws.xa ? ws.xb : ws.xa);
         if (fused) {
             TokenArgs ta;
@@ -1382,6 +1384,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     }
     for (auto& w : m->wslots)
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
+    if (std::string(key) == "attn_mfma") { attn_mfma_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "winblock") { m->winblock = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { pw_batched_ref() = (int)value; return BDE_OK; }

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
     float* PR = ST + 320;                      // bqkv 192 | sqkv 192 | bproj 64 | bfc1 256 | sfc1 256 | bfc2 64
     int* PIX = reinterpret_cast<int*>(PR + 1024);   // [64] pixel of the workgroup's output tokens, -1 = none
     float* XE = PR + 1024 + 64;                // [64][16] x of the carried pixels (columns 49..63)
+    float* S2 = XE + WB_C * 16;                // [4 row tiles][64 tokens][2] partial sums of x1, x1^2 for LayerNorm2
     float* AO = XT + 4 * WB_C * 16;            // [4][64][16]
     float* HID = KL;                           // [4][256][16]
     float* pbqkv = PR, *psqkv = PR + 192, *pbproj = PR + 384, *pbfc1 = PR + 448, *psfc1 = PR + 704, *pbfc2 = PR + 960;
@@ -196,6 +197,10 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
         s2 += wb_shfl_xor(s2, 1);
         s1 += wb_shfl_xor(s1, 2);
         s2 += wb_shfl_xor(s2, 2);
+        if (mlp_only && u < 64) {                  // x1 = x: LayerNorm2 sums in the layout the proj epilogue leaves
+            S2[(cq * 64 + u) * 2] = cq == 0 ? s1 : 0.f;
+            S2[(cq * 64 + u) * 2 + 1] = cq == 0 ? s2 : 0.f;
+        }
         if (cq == 0 && u < 160) {
             const float mean = s1 * (1.f / WB_C);
             const float var = fmaxf(s2 * (1.f / WB_C) - mean * mean, 0.f);
@@ -389,10 +394,23 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
             for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k4], bq[k4], acc, 0, 0, 0);
             const int row0 = rt * 16 + g4 * 4;
             const bool carried = i == 3 && col >= 1;       // token columns 49..63: x1 = x of a pixel outside every window
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float* xp = XT + (i * WB_C + row0 + r) * 16 + col;
-                *xp = carried ? XE[(row0 + r) * 16 + col - 1] : *xp + acc[r] + pbproj[row0 + r];
+                const float v = carried ? XE[(row0 + r) * 16 + col - 1] : *xp + acc[r] + pbproj[row0 + r];
+                *xp = v;
+                s1 += v;
+                s2 += v * v;
+            }
+            // LayerNorm2 sums over this wave's 16 rows; the four row tiles are added in a fixed order by fc1
+            s1 += wb_shfl_xor(s1, 16);
+            s2 += wb_shfl_xor(s2, 16);
+            s1 += wb_shfl_xor(s1, 32);
+            s2 += wb_shfl_xor(s2, 32);
+            if (lane < 16) {
+                S2[(rt * 64 + i * 16 + col) * 2] = s1;
+                S2[(rt * 64 + i * 16 + col) * 2 + 1] = s2;
             }
         }
         wb_sync();
@@ -408,24 +426,22 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
             ss[r] = psfc1[row0 + r];
             bb[r] = pbfc1[row0 + r];
         }
-#pragma unroll 1
+#pragma unroll 2
         for (int i = 0; i < 4; ++i) {
             float bq[16];
 #pragma unroll
             for (int k4 = 0; k4 < 16; ++k4) bq[k4] = XT[(i * WB_C + k4 * 4 + g4) * 16 + col];
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int k4 = 0; k4 < 16; ++k4) {
-                s1 += bq[k4];
-                s2 += bq[k4] * bq[k4];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[k4], bq[k4], acc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                const float2 pp = *reinterpret_cast<const float2*>(S2 + (t * 64 + i * 16 + col) * 2);
+                s1 += pp.x;
+                s2 += pp.y;
             }
-            s1 += wb_shfl_xor(s1, 16);
-            s2 += wb_shfl_xor(s2, 16);
-            s1 += wb_shfl_xor(s1, 32);
-            s2 += wb_shfl_xor(s2, 32);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[k4], bq[k4], acc, 0, 0, 0);
             const float mu = s1 * (1.f / WB_C);
             const float rs = 1.0f / sqrtf(fmaxf(s2 * (1.f / WB_C) - mu * mu, 0.f) + 1e-5f);
 #pragma unroll
@@ -513,7 +529,7 @@ static int nchw_to_tok(const float* in, float* out, int N, int C, int HW, hipStr
 }
 
 constexpr size_t winblock_lds_bytes() {
-    return (size_t)(2 * WB_NT * WB_C * 16 + 160 * WB_VP + 4 * WB_C * 16 + 320 + 1024 + 64 + WB_C * 16) * sizeof(float);
+    return (size_t)(2 * WB_NT * WB_C * 16 + 160 * WB_VP + 4 * WB_C * 16 + 320 + 1024 + 64 + WB_C * 16 + 512) * sizeof(float);
 }
 
 static int winblock_launch(WinArgs a, int B, hipStream_t stream) {

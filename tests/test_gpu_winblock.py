@@ -26,14 +26,14 @@ def model_a():
     return cfg, sd, build_model(cfg, sd, 'cuda:0')
 
 
-def oracle_blocks(cfg, sd, bufs, first, n):
+def oracle_blocks(cfg, sd, bufs, first, n, level=0):
     from oracle import bde2vid_oracle as O
     rel = torch.from_numpy(relative_position_index(cfg.frame_num, 7, 7))
     keys = [b if b is not None else torch.zeros_like(bufs[cfg.q_idx]) for b in bufs]
     x = keys[cfg.q_idx]
     for i in range(first, first + n):
         keys[cfg.q_idx] = x
-        x = O.swin_block(torch.stack(keys, 0), sd, f'{O.P}feat_attns.0.blocks.{i}.', cfg.num_heads, cfg.q_idx, i % 2 == 1, 7, rel)
+        x = O.swin_block(torch.stack(keys, 0), sd, f'{O.P}feat_attns.{level}.blocks.{i}.', cfg.num_heads, cfg.q_idx, i % 2 == 1, 7, rel)
     return x
 
 
@@ -96,3 +96,24 @@ def test_inputs_untouched_and_deterministic(model_a):
     assert torch.equal(y0, y1)
     for a, b in zip(dev, keep):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(1, 256, 7, 9), (2, 256, 23, 30), (1, 256, 15, 16)])
+def test_level2_matrix_core_attention_vs_oracle(model_a, shape):
+    """Head dim 16 (level 2 of config A): attention core on the matrix cores (csrc/attn_mfma.h) against the
+    oracle and against the vector-ALU core (csrc/attn.h)."""
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    bufs = [torch.from_numpy(dense_like(shape, 380 + d)) for d in range(3)]
+    dev = [b.cuda() for b in bufs]
+    ref = oracle_blocks(cfg, sd, bufs, 0, 2, level=2)
+    y = ops.dframe_attention(m, 2, dev, 0, 2)
+    assert maxabs(y, ref) <= TOL
+    m.set_tuning('attn_mfma', 0)
+    try:
+        y_valu = ops.dframe_attention(m, 2, dev, 0, 2)
+    finally:
+        m.set_tuning('attn_mfma', 1)
+    assert maxabs(y, y_valu.cpu()) <= TOL
+    ref0 = oracle_blocks(cfg, sd, [None, bufs[1], None], 0, 2, level=2)
+    assert maxabs(ops.dframe_attention(m, 2, [None, dev[1], None], 0, 2), ref0) <= TOL
