@@ -53,30 +53,7 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(const AttnArgs a) {
     }
     const float* bias = a.biasT + (long)head * nkey * ATT_TOK + min(qi, ATT_TOK - 1);
 
-    // ---- stage K|V: thread = (key u, 4-channel group cg); 160 keys x 4 groups = 640 items --------------
-    for (int it = tid; it < NT * 16 * 4; it += 256) {
-        const int u = it >> 2, cg = it & 3;
-        float kv[4], vv[4];
-        const int d = u / ATT_TOK, tok = u - d * ATT_TOK;
-        const int pix = u < nkey ? token_pixel(tok) : -1;
-        const float* kp = u < nkey ? a.kv[d] : nullptr;
-        const bool use = pix >= 0 && kp != nullptr;
-        // pointer select + unconditional loads (a load under a per-lane branch costs a vmcnt(0) join)
-        const float* ksrc = use ? kp + b * a.kv_bs[d] + (long)(c0 + cg * 4) * HW + pix : a.kvpad + c0 + cg * 4;
-        const float* vsrc = use ? ksrc + a.v_off[d] : a.kvpad + a.C + c0 + cg * 4;
-        const long cs = use ? (long)HW : 1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            kv[e] = ksrc[e * cs];
-            vv[e] = vsrc[e * cs];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) KL[((u >> 4) * HD + cg * 4 + e) * 16 + (u & 15)] = kv[e];
-        *reinterpret_cast<float4*>(VL + u * HD + cg * 4) = float4{vv[0], vv[1], vv[2], vv[3]};
-    }
-    __syncthreads();
-
-    // ---- pass 1: scores of all key tiles (registers), maximum per query ------------------------------
+    // ---- bias tiles (the C operands of pass 1) are independent of the staging: issue them first ----------
     am_f32x4 sc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -87,6 +64,43 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(const AttnArgs a) {
             sc[j][r] = u < nkey ? bv : -1e30f;
         }
     }
+
+    // ---- stage K|V: thread = (key u, 4-channel group cg); 160 keys x 4 groups = 640 items, all loads of a
+    //      thread's three items in flight together ------------------------------------------------------
+    {
+        float kv[3][4], vv[3][4];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int it = min(tid + t * 256, NT * 16 * 4 - 1);
+            const int u = it >> 2, cg = it & 3;
+            const int d = u / ATT_TOK, tok = u - d * ATT_TOK;
+            const int pix = u < nkey ? token_pixel(tok) : -1;
+            const float* kp = u < nkey ? a.kv[d] : nullptr;
+            const bool use = pix >= 0 && kp != nullptr;
+            // pointer select + unconditional loads (a load under a per-lane branch costs a vmcnt(0) join)
+            const float* ksrc = use ? kp + b * a.kv_bs[d] + (long)(c0 + cg * 4) * HW + pix : a.kvpad + c0 + cg * 4;
+            const float* vsrc = use ? ksrc + a.v_off[d] : a.kvpad + a.C + c0 + cg * 4;
+            const long cs = use ? (long)HW : 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kv[t][e] = ksrc[e * cs];
+                vv[t][e] = vsrc[e * cs];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int it = tid + t * 256;
+            if (it < NT * 16 * 4) {
+                const int u = it >> 2, cg = it & 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) KL[((u >> 4) * HD + cg * 4 + e) * 16 + (u & 15)] = kv[t][e];
+                *reinterpret_cast<float4*>(VL + u * HD + cg * 4) = float4{vv[t][0], vv[t][1], vv[t][2], vv[t][3]};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: scores of all key tiles (registers), maximum per query ------------------------------
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll

@@ -188,7 +188,8 @@ static long pack16(Arena& ar, const float* w, int rows, int K) {
 }
 
 // Weight fragments of the recurrent step kernel (lstm16.h):
-// [hidden16 block][chunk of 8 channels][tap][k4][gate][64], lane l = W[gate*Ch + hb*16 + (l&15)][chunk*8 + k4*4 + (l>>4)][tap].
+// [hidden16 block][chunk of 8 channels][tap][k4][64 lanes][gate], lane l = W[gate*Ch + hb*16 + (l&15)][chunk*8 + k4*4 + (l>>4)][tap]
+// (the four gate fragments of a lane are adjacent: one 16-byte LDS read fetches them).
 static PackedLayer pack_lstm16(Arena& ar, const std::vector<const DenseLayer*>& groups) {
     const DenseLayer& d0 = *groups[0];
     PackedLayer pl;
@@ -214,7 +215,7 @@ static PackedLayer pack_lstm16(Arena& ar, const std::vector<const DenseLayer*>& 
                         for (int gate = 0; gate < 4; ++gate)
                             for (int l = 0; l < 64; ++l) {
                                 const int hc = hb * 16 + (l & 15), ci = ch * 8 + k4 * 4 + (l >> 4);
-                                const long o = ((((long)(hb * pl.nchunks + ch) * 9 + tap) * 2 + k4) * 4 + gate) * 64 + l;
+                                const long o = ((((long)(hb * pl.nchunks + ch) * 9 + tap) * 2 + k4) * 64 + l) * 4 + gate;
                                 dst[o] = (hc < Ch && ci < d.Cin) ? d.w[((long)(gate * Ch + hc) * d.Cin + ci) * 9 + tap] : 0.f;
                             }
         std::copy(d.bias.begin(), d.bias.end(), ar.host.begin() + pl.b_off + (long)g * d0.rows);

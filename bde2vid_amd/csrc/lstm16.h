@@ -9,7 +9,7 @@
 // the weight fragments and the halo tile both staged through LDS (shared by the four waves, next stage
 // prefetched into ~25 registers) the kernel runs at 5+ waves/SIMD, and a level-0 step of config A is
 // 1472 workgroups of equal cost -- the 32x32 version was register-bound at 2 waves/SIMD.
-//   A = packed weights  [hidden16 block][channel chunk 8][tap 9][k4 2][gate 4][64 lanes],
+//   A = packed weights  [hidden16 block][channel chunk 8][tap 9][k4 2][64 lanes][gate 4]  (ds_read_b128 = four fragments),
 //       lane l = W[gate*Ch + hb*16 + (l&15)][ci = chunk*8 + k4*4 + (l>>4)][tap]
 //   B = LDS halo tile [8 channels][3 rows][66 cols], plane stride padded to 16 mod 32 floats so the
 //       four channel rows of a fragment fall on disjoint banks
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
                 for (int k4 = 0; k4 < 2; ++k4) {
 #pragma unroll
                     for (int sg = 0; sg < SEG; ++sg) bq[buf][k4][sg] = ldsB[bofl + k4 * 4 * PLS + ky * IWP + kx + sg * 16];
-                    const float* ap = ldsA + ((tap * 2 + k4) * 4) * 64 + lane;
+                    const f32x4_ av = *reinterpret_cast<const f32x4_*>(ldsA + ((tap * 2 + k4) * 64 + lane) * 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) aq[buf][k4][q] = ap[q * 64];
+                    for (int q = 0; q < 4; ++q) aq[buf][k4][q] = av[q];
                 }
             };
             frag_read(0, 0);

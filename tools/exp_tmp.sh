@@ -1,6 +1,5 @@
-timeout -k 10 400 python -m pytest tests/test_gpu_winblock.py tests/test_gpu_e2e.py -x -q 2>&1 | tail -3
-tools/kstat.sh am attn2 "attn_"
-for i in 1 2; do
-BDE_TUNING="attn_mfma=0" timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('valu', 'ms/step', round(d['ms_per_step'],2), 'fps', round(d['value'],1))"
-timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mfma', 'ms/step', round(d['ms_per_step'],2), 'fps', round(d['value'],1))"
+timeout -k 10 400 python -m pytest tests/test_gpu_blocks.py tests/test_gpu_e2e.py -x -q 2>&1 | tail -3
+for st in lstm0 lstm1 lstm2; do
+BDE_LIB_PATH=$PWD/ab_build/lib_HEAD.so tools/kstat.sh old_$st $st "lstm16"
+tools/kstat.sh new_$st $st "lstm16"
 done
