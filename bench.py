@@ -55,6 +55,21 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def lstm_shape(ho, wo, ch, B):
+    """Tile shape csrc/lstm16.h picks for a [ch][ho][wo] hidden map (mirrors lstm16_launch; label only)."""
+    cdiv = lambda a, b: -(-a // b)
+    fill = lambda r, p: ho * cdiv(wo, 16) / (cdiv(ho, r) * cdiv(wo, p) * (r * p // 16))
+    rows, pxw, bf = 1, 64, -1.0
+    for r, p in ((1, 64), (2, 32), (4, 16)):
+        f = fill(r, p)
+        if f > bf + 0.02:
+            bf, rows, pxw = f, r, p
+    seg = 1
+    if cdiv(ho, rows) * cdiv(wo, pxw) * cdiv(ch, 16) * 2 * B > 1024 and fill(1, 128) >= bf - 0.08:
+        rows, pxw, seg = 1, 128, 2
+    return f'{rows},{pxw},{seg}'
+
+
 def lstm_flops_per_launch(cfg, B, H, W, level):
     """Algorithmic flops of ONE recurrent ConvLSTM step launch (both directions):
     h-part of the gates conv, 2 * (4C) * C * 9 per pixel, plus ~20 flop/px/channel pointwise."""
@@ -188,7 +203,7 @@ def main():
         achieved = fl / avg_s / 1e12 if avg_s > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (raw counters)
-            with open(os.path.join(REPO, 'profiles', 'r1_lstm0_pmc.json')) as f:
+            with open(os.path.join(REPO, 'profiles', 'r1b_lstm0_pmc.json')) as f:
                 traffic = json.load(f)['hbm_bytes_per_launch_raw']
         except Exception:
             pass
@@ -204,7 +219,7 @@ def main():
                        'parallelism': f'{world} replicas, sequences sharded, 1 RCCL weight broadcast; per GPU '
                                       f'{args.pipeline} independent sequence(s) in flight (double-buffered workspaces), '
                                       f'launch sequence replayed from a hipGraph'},
-            'roofline': {'kernel': 'lstm16_step_kernel<1,64> (level-0 recurrent ConvLSTM step, both directions)',
+            'roofline': {'kernel': f'lstm16_step_kernel<{lstm_shape(H // 2, W // 2, cfg.basechannels * 2, B)}> (level-0 recurrent ConvLSTM step, both directions)',
                          'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'launches': int(cnt.value), 'avg_us': avg_s * 1e6, 'flops_per_launch': fl,

@@ -1,5 +1,3 @@
-timeout -k 10 400 python -m pytest tests/test_gpu_blocks.py tests/test_gpu_e2e.py -x -q 2>&1 | tail -3
-for st in lstm0 lstm1 lstm2; do
-BDE_LIB_PATH=$PWD/ab_build/lib_HEAD.so tools/kstat.sh old_$st $st "lstm16"
-tools/kstat.sh new_$st $st "lstm16"
-done
+tools/gpu_pmc.sh r1b_fetch lstm0 "FETCH_SIZE" > gpurun_out/r1b_pmc_fetch.txt 2>&1
+tools/gpu_pmc.sh r1b_tcc lstm0 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" > gpurun_out/r1b_pmc_tcc.txt 2>&1
+grep -A3 lstm16 gpurun_out/r1b_pmc_fetch.txt; grep -A4 lstm16 gpurun_out/r1b_pmc_tcc.txt
