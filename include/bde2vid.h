@@ -102,7 +102,13 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *   "graph": 1 (default) replays the launch sequence of a forward from a hipGraph captured at the second
  *              call of a shape; 0 launches eagerly.
  *   "fused_min_tiles": a level with at least this many 32-pixel tiles runs the post-softmax part of an
- *                      attention block as one fused kernel instead of three GEMM launches (default 160). */
+ *                      attention block as one fused kernel instead of three GEMM launches (default 160).
+ *   "winblock": 1 (default) runs an attention block of a 64-channel / 16-head level as ONE launch
+ *               (csrc/winblock.h); 0 keeps the split path (attention core + fused token kernel).
+ *   "attn_mfma": 1 (default) uses the matrix-core attention core for head_dim 16 (csrc/attn_mfma.h).
+ * Diagnostics only (results become wrong): "debug_skip" = bit mask of stages left out of a forward
+ * (1 attention level 0, 2 attention levels >= 1, 4 recurrent steps, 8 decoder, 16 encoder + gate convs),
+ * used by tools/whatif.sh to read the marginal cost of a stage. */
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 
 /* Diagnostics: resident workgroups per CU the runtime reports for a named kernel (-1 = unknown). */
