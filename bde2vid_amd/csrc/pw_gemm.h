@@ -131,55 +131,51 @@ __global__ __launch_bounds__(WS == 1 ? 256 : 64 * WS) void pw_gemm_kernel(const 
     const int r0 = SPLIT ? (wave & 3) * 4 : 0;
     float fin[MT][NT][RPW];
     if constexpr (SPLIT) {
-        // one register quarter per phase: every wave publishes registers [4q,4q+4) of its tiles,
-        // wave q sums the WS copies (waves >= 4 only contribute partial sums)
-        constexpr int LNOFF = WS * MT * NT * 256;
+        // every wave publishes its whole partial tile once; after ONE barrier wave q sums register
+        // quarter [4q, 4q+4) over the WS copies (these launches sit on the sequential attention chain:
+        // the earlier quarter-per-phase scheme cost eight barriers for a quarter of the LDS)
+        constexpr int LNOFF = WS * MT * NT * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q) __syncthreads();
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int rr = 0; rr < 16; ++rr)
+                    lds[((((wave * MT + m) * NT + t) * 16) + rr) * 64 + lane] = acc[m][t][rr];
+        if (want_ln) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-                        lds[((((wave * MT + m) * NT + t) * 4) + rr) * 64 + lane] = acc[m][t][4 * q + rr];
-            if (want_ln && q == 0) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    lds[LNOFF + (wave * NT + t) * 128 + lane] = s1[t];
-                    lds[LNOFF + (wave * NT + t) * 128 + 64 + lane] = s2[t];
-                }
-            }
-            __syncthreads();
-            if (wave == q) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            float v = 0.f;
-#pragma unroll
-                            for (int w = 0; w < WS; ++w) v += lds[((((w * MT + m) * NT + t) * 4) + rr) * 64 + lane];
-                            fin[m][t][rr] = v;
-                        }
-            }
-            if (want_ln && q == 0) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    float u = 0.f, v = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WS; ++w) {
-                        u += lds[LNOFF + (w * NT + t) * 128 + lane];
-                        v += lds[LNOFF + (w * NT + t) * 128 + 64 + lane];
-                    }
-                    s1[t] = u;
-                    s2[t] = v;
-                }
+            for (int t = 0; t < NT; ++t) {
+                lds[LNOFF + (wave * NT + t) * 128 + lane] = s1[t];
+                lds[LNOFF + (wave * NT + t) * 128 + 64 + lane] = s2[t];
             }
         }
-        if (wave >= 4) return;                    // only waves 0..3 hold finished rows
+        __syncthreads();
+        if (wave >= 4) return;                    // only waves 0..3 finish rows
+        const int q = wave & 3;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WS; ++w) v += lds[((((w * MT + m) * NT + t) * 16) + 4 * q + rr) * 64 + lane];
+                    fin[m][t][rr] = v;
+                }
+        if (want_ln) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float u = 0.f, v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WS; ++w) {
+                    u += lds[LNOFF + (w * NT + t) * 128 + lane];
+                    v += lds[LNOFF + (w * NT + t) * 128 + 64 + lane];
+                }
+                s1[t] = u;
+                s2[t] = v;
+            }
+        }
     } else {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(WS == 1 ? 256 : 64 * WS) void pw_gemm_kernel(const 
 template <int MT, int NT, int WS>
 static int pw_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
     constexpr int BN = (WS > 1 ? 1 : 4) * NT * 32;
-    const size_t lds = WS > 1 ? (size_t)(WS * MT * NT * 256 + WS * NT * 128) * sizeof(float) : 0;
+    const size_t lds = WS > 1 ? (size_t)(WS * MT * NT * 1024 + WS * NT * 128) * sizeof(float) : 0;
     dim3 grid(cdiv(a.Wo, BN), cdiv(a.Cout, MT * 32), G * a.N);
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
     hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WS>), grid, dim3(WS > 1 ? 64 * WS : 256), lds, stream, a);
@@ -246,7 +242,6 @@ static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
     const long t1 = px_tiles * cdiv(a.Cout, 32) * frames;     // wave tasks with MT = 1
     // T-batched launches are bound by their output stores (K is only 64..256): the lean one-tile-per-
     // wave variant (4 waves/SIMD) measured ahead of the register-heavy 2x2 and 2x1 ones
-    if (t1 >= 768) return pw_launch_t<1, 1, 1>(a, G, stream);
     if (t1 >= 768) return pw_launch_t<1, 1, 1>(a, G, stream);
     // few tiles (one frame of a small map): split K over the waves of a block; one 32x32 tile per
     // wave measured faster than two on the level-2 chain (more blocks, shorter per-wave chains)

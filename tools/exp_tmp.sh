@@ -1,3 +1,7 @@
-tools/gpu_pmc.sh r1b_fetch lstm0 "FETCH_SIZE" > gpurun_out/r1b_pmc_fetch.txt 2>&1
-tools/gpu_pmc.sh r1b_tcc lstm0 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" > gpurun_out/r1b_pmc_tcc.txt 2>&1
-grep -A3 lstm16 gpurun_out/r1b_pmc_fetch.txt; grep -A4 lstm16 gpurun_out/r1b_pmc_tcc.txt
+timeout -k 10 400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for i in 1 2; do
+BDE_TUNING="kv_ride=0" timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('noride', 'ms/step', round(d['ms_per_step'],2), 'fps', round(d['value'],1))"
+timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ride', 'ms/step', round(d['ms_per_step'],2), 'fps', round(d['value'],1))"
+done
+BDE_TUNING="kv_ride=0" timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --pipeline 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('noride p1', 'ms/step', round(d['ms_per_step'],2), 'fps', round(d['value'],1))"
+timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --pipeline 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ride p1', 'ms/step', round(d['ms_per_step'],2), 'fps', round(d['value'],1))"
