@@ -46,6 +46,7 @@ SIGNATURES = {
     'bde_profile_get': (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_L)]),
     'bde_voxelize': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'bde_voxelize_batch': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
+    'bde_voxelize_events': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
     'bde_op_head': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'bde_op_recurrent_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     'bde_op_encoder_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),

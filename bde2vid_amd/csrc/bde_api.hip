@@ -1501,6 +1501,16 @@ int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const 
                         oob_count, (hipStream_t)stream);
 }
 
+int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, const int64_t* offsets,
+                        int32_t nwin, int64_t max_events_per_window, int32_t num_bins, int32_t H, int32_t W, float* grids,
+                        int32_t* oob_count, void* stream) {
+    BDE_REQUIRE(grids && offsets && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
+    BDE_REQUIRE(max_events_per_window <= 0 || (xs && ys && ts && ps), "null event column");
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
+    return voxel_native_launch(xs, ys, ts, ps, (const long*)offsets, nwin, (long)max_events_per_window, num_bins, H, W, grids,
+                               oob_count, (hipStream_t)stream);
+}
+
 // ---- single sub-modules ----------------------------------------------------------------------
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out, "bad argument");

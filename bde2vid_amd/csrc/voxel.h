@@ -62,6 +62,69 @@ __global__ __launch_bounds__(256) void voxel_scatter_kernel(const float* __restr
     }
 }
 
+// The same binning straight from the recording's native event columns (Monash HDF5 schema read by
+// DynamicH5Dataset.get_events, data_loader/h5_dataset.py:410-415: xs, ys int16, ts float64 seconds, ps bool),
+// one grid per between-frames window [offsets[w], offsets[w+1]) of the event stream -- the slicing of
+// BaseVoxelDataset.__getitem__ (:213-226) done on the device: 13 B read per event instead of the 16 B of four
+// float32 columns plus the host-side casts.  Restated per window:
+//   fewer than 3 events -> all-zero grid                                   (:219-220)
+//   ts -> float32(ts - ts[first])  (subtraction in float64, then the cast)  (:224)
+//   ps -> +1 / -1                  (ps * 2.0 - 1.0, :414; float32 cast :225)
+//   then events_to_voxel_torch on the float32 columns                       (:357)
+__global__ __launch_bounds__(256) void voxel_scatter_native_kernel(const short* __restrict__ xs, const short* __restrict__ ys,
+                                                                   const double* __restrict__ ts,
+                                                                   const unsigned char* __restrict__ ps,
+                                                                   const long* __restrict__ offsets, int nb, int H, int W,
+                                                                   float* __restrict__ grids, int* __restrict__ oob) {
+    const int seg = blockIdx.y;
+    const long beg = offsets[seg], end = offsets[seg + 1];
+    if (end - beg < 3) return;
+    float* grid = grids + (long)seg * nb * H * W;
+    const double t0d = ts[beg];
+    const float dt = (float)(ts[end - 1] - t0d) - 0.0f;      // event_utils.py:489 on the shifted float32 column
+    const float bm1 = (float)(nb - 1);
+    const long HW = (long)H * W;
+    for (long i = beg + blockIdx.x * (long)blockDim.x + threadIdx.x; i < end; i += (long)gridDim.x * blockDim.x) {
+        const float tn = ((float)(ts[i] - t0d) - 0.0f) / dt * bm1;
+        long xi = (long)xs[i], yi = (long)ys[i];
+        if (xi < 0) xi += W;                               // index_put_ wraps negative indices
+        if (yi < 0) yi += H;
+        if (xi < 0 || xi >= W || yi < 0 || yi >= H) {      // the reference raises IndexError here
+            if (oob) atomicAdd(oob, 1);
+            continue;
+        }
+        const float p = ps[i] ? 1.0f : -1.0f;
+        float* cell = grid + yi * W + xi;
+        if (!(tn == tn)) {                                 // dt == 0 -> NaN weights in every bin
+            for (int b = 0; b < nb; ++b) atomicAdd(cell + b * HW, p * tn);
+            continue;
+        }
+        const int b0 = (int)floorf(tn);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b0 + k;
+            if (b < 0 || b >= nb) continue;
+            const float w = fmaxf(0.f, 1.0f - fabsf(tn - (float)b));
+            const float v = p * w;
+            if (v != 0.f) atomicAdd(cell + b * HW, v);
+        }
+    }
+}
+
+static inline int voxel_native_launch(const short* xs, const short* ys, const double* ts, const unsigned char* ps,
+                                      const long* offsets, int nseg, long n_per_seg_max, int nb, int H, int W, float* grids,
+                                      int* oob, hipStream_t stream) {
+    BDE_HIP(hipMemsetAsync(grids, 0, sizeof(float) * (size_t)nseg * nb * H * W, stream));
+    if (oob) BDE_HIP(hipMemsetAsync(oob, 0, sizeof(int), stream));
+    if (n_per_seg_max <= 0 || nseg <= 0) return BDE_OK;
+    long blocks = cdivl(n_per_seg_max, 256);
+    if (blocks > 2048) blocks = 2048;                  // grid-stride the rest
+    hipLaunchKernelGGL(voxel_scatter_native_kernel, dim3((unsigned)blocks, (unsigned)nseg), dim3(256), 0, stream, xs, ys, ts, ps,
+                       offsets, nb, H, W, grids, oob);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
 static inline int voxel_launch(const float* xs, const float* ys, const float* ts, const float* ps,
                                const long* offsets, int nseg, long n_per_seg_max, int nb, int H, int W,
                                float* grids, int* oob, hipStream_t stream) {

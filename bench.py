@@ -80,7 +80,7 @@ def lstm_flops_per_launch(cfg, B, H, W, level):
 
 def synth_voxels(T, H, W, sensor_hw, device, seed0=1000):
     from bde2vid_amd.events import events_to_voxel_batch
-    from oracle.voxel_oracle import synthetic_events   # input generator only
+    from bde2vid_amd.synth import synthetic_events
     sh, sw = sensor_hw
     packs = [synthetic_events(sh * sw // 2, sh, sw, seed0 + t) for t in range(T)]
     off = np.cumsum([0] + [len(p[0]) for p in packs])
@@ -94,6 +94,28 @@ def synth_voxels(T, H, W, sensor_hw, device, seed0=1000):
     out = torch.zeros((T, 1, 5, H, W), device=device)
     out[:, 0, :, pt:pt + sh, pl:pl + sw] = grids
     return out, int(off[-1]), dt
+
+
+def voxel_native_rate(T, sensor_hw, device, reps=20):
+    """Events/s of the native-column scatter (bde_voxelize_events) with the columns resident in HBM."""
+    from bde2vid_amd.events import events_to_voxel_windows
+    from bde2vid_amd.synth import synthetic_recording
+    sh, sw = sensor_hw
+    n = T * (sh * sw // 2)
+    xs, ys, ts, ps, _ = synthetic_recording(n, sh, sw, 4, 77)
+    idx = np.arange(T + 1, dtype=np.int64) * (n // T)
+    cols = [torch.from_numpy(a).to(device) for a in (xs, ys, ts, ps)]
+    events_to_voxel_windows(*cols, idx, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        events_to_voxel_windows(*cols, idx, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    bytes_per_call = n * 13 + n * 2 * 4 + T * 5 * sh * sw * 4      # columns + two float atomics per event + zero-fill
+    return dict(events_per_s=n / dt, events=n, windows=T, GBps=bytes_per_call / dt / 1e9,
+                note='int16/int16/float64/bool columns resident in HBM, one grid per window, zero-fill included; '
+                     '13 B read + 2 float atomics per event')
 
 
 def cpu_baseline(cfg, sd, H, W, T):
@@ -127,7 +149,7 @@ def main():
     from bde2vid_amd import canonical, _lib
     from bde2vid_amd.dist import init_from_env, build_replicated_model, max_over_ranks, barrier
     from bde2vid_amd.weights import formula_state_dict
-    from oracle.bde2vid_oracle import crop_params
+    from bde2vid_amd.harness import Croper
 
     log('start')
     rank, world, local = init_from_env()
@@ -147,8 +169,9 @@ def main():
             model.set_tuning(k, int(v))
     log('weights packed and resident')
 
-    cp = crop_params(args.width, args.height, cfg.num_encoders)
-    H, W, T, B = cp['hc'], cp['wc'], args.seq_len, args.batch
+    croper = Croper(cfg.num_encoders)
+    croper.update_params(args.width, args.height)
+    H, W, T, B = croper.height_crop_size, croper.width_crop_size, args.seq_len, args.batch
     vox, n_events, vox_dt = synth_voxels(T, H, W, (args.height, args.width), device, seed0=1000 + 97 * rank)
     if B > 1:
         vox = vox.repeat(1, B, 1, 1, 1)
@@ -226,7 +249,8 @@ def main():
                          'measured': 'HIP events on the launch stream around each launch, over 3 eager un-pipelined '
                                      'steps run right after the timed region (events inside hipGraph replays cannot be read)'},
             'voxelize': {'events_per_s': n_events / vox_dt, 'events': n_events,
-                         'note': 'HIP scatter incl. H2D of the events; outside the timed region'},
+                         'note': 'HIP scatter incl. H2D of the events; outside the timed region',
+                         'native_columns': voxel_native_rate(T, (args.height, args.width), device)},
         }
         if world == 1 and not args.no_cpu_baseline:
             log(f'cpu baseline on {host_cores()} host cores ...')

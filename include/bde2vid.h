@@ -14,9 +14,10 @@
  *   bde_forward
  *       <- BDE2VID.forward(inputs, mode='tensor')               model/BDE2VID/bde2vid.py:30-50
  *          == BDE2VIDCrossscalePropogationV5.forward            ..._V5.py:100-241
- *   bde_voxelize / bde_voxelize_batch
+ *   bde_voxelize / bde_voxelize_batch / bde_voxelize_events
  *       <- events_to_voxel_torch                                events_contrast_maximization/utils/event_utils.py:466-509
- *          (+ events_to_image_torch nearest branch, :330-376), called from data_loader/h5_dataset.py:357
+ *          (+ events_to_image_torch nearest branch, :330-376), called from data_loader/h5_dataset.py:357;
+ *          bde_voxelize_events also covers the caller's slicing and casts, h5_dataset.py:213-226,410-415
  *   bde_op_*  (one reference sub-module each; used by the per-block parity tests)
  *       <- ConvLayer.forward            model/BDE2VID/submodules.py:105-114
  *          RecurrentConv.forward        model/BDE2VID/submodules.py:191-195 (+ConvLSTM.forward :293-334)
@@ -133,6 +134,17 @@ int bde_voxelize(const float* xs, const float* ys, const float* ts, const float*
 int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const float* ps,
                        const int64_t* offsets, int32_t nseg, int64_t max_events_per_seg, int32_t num_bins,
                        int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream);
+
+/* The same grids straight from a recording's native event columns (Monash HDF5 schema,
+ * data_loader/h5_dataset.py:410-415: xs, ys int16, ts float64 seconds, ps bool as one byte), one grid per
+ * between-frames window: window w owns events [offsets[w], offsets[w+1]) (device int64 [nwin+1], e.g. the
+ * images' `event_idx` attributes) and writes grids[w].  Restates BaseVoxelDataset.__getitem__
+ * (h5_dataset.py:213-226: fewer than 3 events -> zero grid; ts - ts[first] in float64, then float32;
+ * ps*2-1) followed by get_voxel_grid (:343-366) with the default all-ones hot-pixel mask.
+ * All pointers are device pointers; max_events_per_window sizes the launch. */
+int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps,
+                        const int64_t* offsets, int32_t nwin, int64_t max_events_per_window, int32_t num_bins,
+                        int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream);
 
 /* ---- single reference sub-modules (parity tests) ------------------------------------------- */
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream);

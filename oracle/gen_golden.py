@@ -165,6 +165,38 @@ def gen_voxels():
     print('voxel', {k: v.shape for k, v in out.items()})
 
 
+RECORDING_CASES = {
+    # name: (N, H, W, nwin, seed)
+    'rec_small': (4000, 30, 40, 7, 21),
+    'rec_davis': (60000, 180, 240, 9, 22),
+}
+
+
+def gen_recording_voxels():
+    """Native event columns (int16 / float64 / bool) -> one voxel grid per between-frames window.
+    The casts are the reference's own lines (data_loader/h5_dataset.py:219-225 with get_events :410-415:
+    h5py, which that module imports, is not installed, so the four lines are applied here verbatim in
+    meaning); the binning is the reference's events_to_voxel_torch, imported and called."""
+    EU = ref_import.import_event_utils()
+    out = {}
+    for name, (N, H, W, nwin, seed) in RECORDING_CASES.items():
+        xs, ys, ts, ps, idx = voxel_oracle.synthetic_recording(N, H, W, nwin, seed)
+        psf = ps * 2.0 - 1.0                                                  # :414
+        grids = np.zeros((len(idx) - 1, 5, H, W), dtype=np.float32)
+        for w in range(len(idx) - 1):
+            i0, i1 = int(idx[w]), int(idx[w + 1])
+            if i1 - i0 < 3:                                                   # :219-220
+                continue
+            x = torch.from_numpy(xs[i0:i1].astype(np.float32))                # :222
+            y = torch.from_numpy(ys[i0:i1].astype(np.float32))                # :223
+            t = torch.from_numpy((ts[i0:i1] - ts[i0]).astype(np.float32))     # :224
+            p = torch.from_numpy(psf[i0:i1].astype(np.float32))               # :225
+            grids[w] = EU.events_to_voxel_torch(x, y, t, p, 5, sensor_size=(H, W)).numpy()   # :357
+        out[name] = grids
+    np.savez_compressed(os.path.join(OUT, 'voxel_recording.npz'), **out)
+    print('voxel_recording', {k: v.shape for k, v in out.items()})
+
+
 def gen_croper():
     Croper = ref_import.import_croper()
     res = {}
@@ -191,5 +223,6 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     gen_croper()
     gen_voxels()
+    gen_recording_voxels()
     gen_blocks()
     gen_e2e()

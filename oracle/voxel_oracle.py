@@ -36,13 +36,28 @@ def events_to_voxel(xs, ys, ts, ps, num_bins, sensor_size):
     return out
 
 
-def synthetic_events(n, height, width, seed):
-    """Synthetic event packet of SURVEY.md §8(d): x~U{0..W-1}, y~U{0..H-1} as float32 integers,
-    t = sorted U(0,1) float32 minus first, p in {-1,+1}."""
-    rng = np.random.default_rng(seed)
-    xs = rng.integers(0, width, n).astype(np.float32)
-    ys = rng.integers(0, height, n).astype(np.float32)
-    ts = np.sort(rng.random(n, dtype=np.float32))
-    ts = (ts - ts[0]).astype(np.float32)
-    ps = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
-    return xs, ys, ts, ps
+def between_frames_voxels(xs, ys, ts, ps, event_idx, num_bins, sensor_size):
+    """Voxel grids of consecutive windows from native event columns: the item assembly of
+    BaseVoxelDataset.__getitem__ (data_loader/h5_dataset.py:213-226) on the columns DynamicH5Dataset.get_events
+    returns (:410-415: xs, ys int16; ts float64; ps = bool * 2.0 - 1.0), then get_voxel_grid (:343-366,
+    combined channels, all-ones hot-pixel mask).  Returns float32 [nwin, num_bins, H, W]."""
+    xs = np.asarray(xs)
+    ys = np.asarray(ys)
+    ts = np.asarray(ts, dtype=np.float64)
+    ps = np.asarray(ps).astype(np.float64) * 2.0 - 1.0                      # :414
+    H, W = sensor_size
+    out = np.zeros((len(event_idx) - 1, int(num_bins), H, W), dtype=np.float32)
+    for w in range(len(event_idx) - 1):
+        i0, i1 = int(event_idx[w]), int(event_idx[w + 1])
+        if i1 - i0 < 3:                                                     # :219-220 empty voxel grid
+            continue
+        x = xs[i0:i1].astype(np.float32)                                    # :222
+        y = ys[i0:i1].astype(np.float32)                                    # :223
+        t = (ts[i0:i1] - ts[i0]).astype(np.float32)                         # :224
+        p = ps[i0:i1].astype(np.float32)                                    # :225
+        out[w] = events_to_voxel(x, y, t, p, num_bins, sensor_size)
+    return out
+
+
+# input generators live with the product's host code (bench.py uses them too); re-exported for the tests
+from bde2vid_amd.synth import synthetic_events, synthetic_recording  # noqa: E402,F401

@@ -175,3 +175,28 @@ def test_voxel_scatter_batch_and_oob():
     with pytest.raises(IndexError):
         events_to_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts),
                               torch.from_numpy(ps), 5, device='cuda', sensor_size=(40, 50))
+
+
+@pytest.mark.parametrize('name,case', [('rec_small', (4000, 30, 40, 7, 21)), ('rec_davis', (60000, 180, 240, 9, 22))])
+def test_voxel_windows_from_native_columns(name, case):
+    """bde_voxelize_events: int16 / float64 / bool columns + window boundaries -> grids, against the
+    reference's golden grids (same tolerance as the float32 scatter: only the per-pixel sum order differs)."""
+    import os
+    from bde2vid_amd.events import events_to_voxel_windows
+    from oracle import voxel_oracle
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'voxel_recording.npz'))
+    N, H, W, nwin, seed = case
+    xs, ys, ts, ps, idx = voxel_oracle.synthetic_recording(N, H, W, nwin, seed)
+    g = events_to_voxel_windows(xs, ys, ts, ps, idx, 5, sensor_size=(H, W))
+    assert g.shape == z[name].shape
+    assert maxabs(g, z[name]) <= 1e-4
+    assert float(g[-1].abs().max()) == 0.0 and float(g[-2].abs().max()) == 0.0
+    # device-resident torch columns give the same grids; a coordinate outside the sensor raises
+    g2 = events_to_voxel_windows(torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda(), torch.from_numpy(ts).cuda(),
+                                 torch.from_numpy(ps).cuda(), idx, 5, sensor_size=(H, W))
+    assert maxabs(g2, z[name]) <= 1e-4
+    bad = xs.copy()
+    bad[5] = W
+    with pytest.raises(IndexError):
+        events_to_voxel_windows(bad, ys, ts, ps, idx, 5, sensor_size=(H, W))

@@ -123,3 +123,17 @@ def test_croper_matches_reference():
         assert [p['hc'], p['wc']] == [r['hc'], r['wc']]
         assert list(p['pad']) == r['pad']
         assert list(p['crop']) == r['crop']
+
+
+@pytest.mark.parametrize('name,case', [('rec_small', (4000, 30, 40, 7, 21)), ('rec_davis', (60000, 180, 240, 9, 22))])
+def test_recording_voxels_match_reference(name, case):
+    """Native event columns (int16 / float64 / bool) through the dataset's casts and the reference binning:
+    the restatement is bit-exact, windows with fewer than 3 events are zero grids."""
+    z = np.load(os.path.join(GOLDEN, 'voxel_recording.npz'))
+    N, H, W, nwin, seed = case
+    xs, ys, ts, ps, idx = voxel_oracle.synthetic_recording(N, H, W, nwin, seed)
+    assert xs.dtype == np.int16 and ts.dtype == np.float64 and ps.dtype == bool and len(idx) == nwin + 1
+    v = voxel_oracle.between_frames_voxels(xs, ys, ts, ps, idx, 5, (H, W))
+    assert v.shape == z[name].shape
+    assert np.array_equal(v, z[name])
+    assert not v[-1].any() and not v[-2].any()          # the 2-event and the empty window
