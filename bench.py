@@ -145,6 +145,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipeline', type=int, default=3, help='independent sequences in flight per GPU (1..4)')
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: everything else a library prints there (RCCL's version banner at
+    # communicator creation, for one) is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     from bde2vid_amd import canonical, _lib
     from bde2vid_amd.dist import init_from_env, build_replicated_model, max_over_ranks, barrier
@@ -255,7 +260,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log(f'cpu baseline on {host_cores()} host cores ...')
             out['cpu_baseline'] = cpu_baseline(cfg, sd_holder['sd'], H, W, T)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     barrier()
     import torch.distributed as dist
     if dist.is_initialized():
