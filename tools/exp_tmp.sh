@@ -1,2 +1,5 @@
-BDE_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/dist1.out 2> gpurun_out/dist1.err; echo "rc=$?"; wc -l gpurun_out/dist1.out; head -c 120 gpurun_out/dist1.out; echo; grep -c RCCL gpurun_out/dist1.err
-timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | wc -l
+timeout -k 10 400 python -m pytest tests/test_gpu_blocks.py tests/test_gpu_e2e.py -x -q 2>&1 | tail -3
+for st in lstm0 lstm1 lstm2; do
+LSTM_GLDS=0 tools/kstat.sh reg_$st $st "lstm16"
+tools/kstat.sh glds_$st $st "lstm16"
+done
