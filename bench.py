@@ -234,6 +234,22 @@ def main():
         pointwise = 2 * B * (H >> 1) * (W >> 1) * 20.0 * cfg.enc_out(0)
         flops_total = (cnt.value - n_eager) * fl + n_eager * pointwise
         achieved = flops_total / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # encoder stage of the north star (encoder convs + gate convs + recurrent steps, SURVEY.md §8d: 45.9 GFLOP per
+        # 184x240 frame): HIP-event spans of the same eager steps
+        enc_ms = 0.0
+        for nm in [b'enc_conv', b'gates_x'] + [b'lstm%d' % l for l in range(cfg.num_encoders)]:
+            t_, c_ = C.c_double(), C.c_int64()
+            L.bde_profile_get(model._h, nm, C.byref(t_), C.byref(c_))
+            enc_ms += t_.value
+        enc_flops = 0.0
+        for l in range(cfg.num_encoders):
+            cin, cout = cfg.enc_in(l), cfg.enc_out(l)
+            hw = (H >> (l + 1)) * (W >> (l + 1))
+            # both directions: stride-2 k x k conv, 3x3 gate conv on [x | h], ~20 flop per (pixel, channel) pointwise
+            enc_flops += 2 * B * T * hw * (2.0 * cout * cin * cfg.ks ** 2 + 2.0 * 4 * cout * 2 * cout * 9 + 20.0 * cout)
+        enc_flops -= sum(2 * B * (H >> (l + 1)) * (W >> (l + 1)) * 2.0 * 4 * cfg.enc_out(l) ** 2 * 9 for l in range(cfg.num_encoders))  # h = 0 at the first step
+        enc_flops *= n_eager
+        enc_tf = enc_flops / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (raw counters)
             with open(os.path.join(REPO, 'profiles', 'r1b_lstm0_pmc.json')) as f:
@@ -257,6 +273,10 @@ def main():
                          'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'launches': int(cnt.value), 'avg_us': avg_s * 1e6, 'flops_per_launch': fl,
                          'flops_counted': flops_total,
+                         'encoder_stage': {'what': 'encoder convs + gate convs + recurrent steps of all levels (the fused '
+                                                   'conv+ConvLSTM encoder of the north star), same eager steps',
+                                           'flops': enc_flops, 'ms': enc_ms, 'achieved': enc_tf, 'unit': 'TFLOP/s',
+                                           'frac': enc_tf / FP32_MFMA_PEAK_TFLOPS},
                          'measured': 'HIP events on the launch stream around each launch, over 3 eager un-pipelined '
                                      'steps run right after the timed region (events inside hipGraph replays cannot be read); '
                                      'achieved = flops of all those launches (the first step of a sweep has no contraction) / their total time'},
