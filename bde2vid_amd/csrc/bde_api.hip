@@ -1390,6 +1390,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { pw_batched_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "conv_nt") { conv_vec_nt_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_vec") { conv_vec_enable_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_shape") { lstm16_shape_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }

@@ -221,6 +221,8 @@ static int conv_vec_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 
 // Same tiling choice as conv_launch_ks; returns BDE_ERR_UNSUPPORTED when no vector tiling fits
 // (the caller then falls back to the dword kernel).
+inline int& conv_vec_nt_ref() { static int v = 0; return v; }   // tuning: force 32-pixel tiles per wave (1 | 2), 0 = auto
+
 template <int KS, int STRIDE>
 static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launched) {
     *launched = false;
@@ -231,6 +233,7 @@ static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launc
     int bnt = 1, brow = 0;
     for (int nt = 2; nt >= 1; --nt)
         for (int row = 1; row >= 0; --row) {
+            if (conv_vec_nt_ref() && nt != conv_vec_nt_ref()) continue;
             const int BN = 4 * nt * 32;
             const int rt = row ? cdiv(a.Wo, BN) : 0;
             if (row && rt > 1 && (BN * STRIDE) % 4 != 0) continue;
@@ -238,7 +241,11 @@ static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launc
             const long lds = ((long)MT * KS * KS * (CK / 2) * 64 + (long)CK * tile) * 4;
             if ((tile / 4 + 255) / 256 > CV_MAXI4 || lds > 64 * 1024) continue;
             const double launched_px = row ? (double)a.Ho * rt * BN : (double)cdiv(a.Ho * a.Wo, BN) * BN;
-            double score = (double)a.Ho * a.Wo / launched_px * (nt == 2 ? 1.0 : 0.92);
+            // two 32-pixel tiles per wave reuse each weight fragment twice, but with 64-row tiles they cost a third
+            // of the residency (2 waves/SIMD instead of 3): measured ahead for the 3x3 gate convs, behind for every
+            // 5x5 conv with more than 32 output channels (decoder 128->64 at 92x120: 850 vs 680 us)
+            const double pref = (KS == 5 && MT == 2) ? (nt == 1 ? 1.0 : 0.9) : (nt == 2 ? 1.0 : 0.92);
+            double score = (double)a.Ho * a.Wo / launched_px * pref;
             const long blocks = (long)(launched_px / BN) * cdiv(a.Cout, MT * 32) * G * a.N;
             if (blocks < 512) score *= 0.5 + 0.5 * blocks / 512.0;
             if (score > best) { best = score; bnt = nt; brow = rt; }
