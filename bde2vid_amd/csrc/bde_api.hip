@@ -56,6 +56,43 @@ __global__ __launch_bounds__(256) void add2_tail_kernel(const float* a, const fl
     long i = beg + blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i < n) o[i] = a[i] + b[i];
 }
+// The caller's T frame tensors <-> one contiguous [T][n] stack, one launch per direction (the frame
+// pointers travel by value; 2T separate hipMemcpyAsync calls cost ~7 us each on the stream).
+constexpr int FRAME_PTRS = 64;
+struct FramePtrs { const float* p[FRAME_PTRS]; };
+__global__ __launch_bounds__(256) void gather_frames_kernel(FramePtrs fp, float* __restrict__ dst, long n4, long n) {
+    const float* src = fp.p[blockIdx.y];
+    float* d = dst + (long)blockIdx.y * n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(src)[i];
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) d[i] = src[i];
+}
+__global__ __launch_bounds__(256) void scatter_frames_kernel(FramePtrs fp, const float* __restrict__ srcs, long n4, long n) {
+    float* d = const_cast<float*>(fp.p[blockIdx.y]);
+    const float* src = srcs + (long)blockIdx.y * n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(src)[i];
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) d[i] = src[i];
+}
+// dir 0: frames -> stack, 1: stack -> frames.  Frame pointers must be 16-byte aligned for the float4 path.
+static int copy_frames(const float* const* frames, float* stack, int T, long n, int dir, hipStream_t s) {
+    bool aligned = (n % 4 == 0);
+    for (int t = 0; t < T && aligned; ++t) aligned = ((uintptr_t)frames[t] % 16) == 0;
+    const long n4 = aligned ? n / 4 : 0;
+    for (int t0 = 0; t0 < T; t0 += FRAME_PTRS) {
+        const int nt = std::min(FRAME_PTRS, T - t0);
+        FramePtrs fp;
+        for (int k = 0; k < FRAME_PTRS; ++k) fp.p[k] = frames[t0 + std::min(k, nt - 1)];
+        const unsigned bx = (unsigned)std::min<long>(std::max<long>(cdivl(std::max<long>(n4, n / 4), 256), 1), 256);
+        if (dir == 0) hipLaunchKernelGGL(gather_frames_kernel, dim3(bx, nt), dim3(256), 0, s, fp, stack + (long)t0 * n, n4, n);
+        else hipLaunchKernelGGL(scatter_frames_kernel, dim3(bx, nt), dim3(256), 0, s, fp, stack + (long)t0 * n, n4, n);
+    }
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
 static int add2(const float* a, const float* b, float* o, long n, hipStream_t s) {
     long n4 = n / 4;
     if (n4 > 0) {
@@ -1097,8 +1134,7 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
     BDE_TRY(ensure_workspace(m, T, B, H, W));
     Workspace& ws = m->W();
     const long ev_fs = (long)B * m->cfg.num_bins * H * W, img_fs = (long)B * H * W;
-    for (int t = 0; t < T; ++t)
-        BDE_HIP(hipMemcpyAsync(ws.ev + t * ev_fs, events[t], sizeof(float) * ev_fs, hipMemcpyDeviceToDevice, s));
+    BDE_TRY(copy_frames(events, ws.ev, T, ev_fs, 0, s));
     const bool can_graph = m->use_graph && !m->overlap && ws.warm;   // (profiling spans are captured as event-record nodes)
     if (can_graph && !ws.graph_exec) {
         // capture on a private stream (the caller's may be the legacy default stream, which cannot
@@ -1124,8 +1160,7 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
         BDE_TRY(forward_body(m, T, B, H, W, s));
         ws.warm = true;                       // first call of a shape runs eagerly (one-time kernel attribute setup)
     }
-    for (int t = 0; t < T; ++t)
-        BDE_HIP(hipMemcpyAsync(images[t], ws.out + t * img_fs, sizeof(float) * img_fs, hipMemcpyDeviceToDevice, s));
+    BDE_TRY(copy_frames(images, ws.out, T, img_fs, 1, s));
     return BDE_OK;
 }
 
