@@ -79,6 +79,12 @@ __device__ __forceinline__ float wb_shfl_xor(float v, int m) { return __shfl_xor
 // vmcnt as well).
 __device__ __forceinline__ void wb_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// max of three without the quieting copies fmaxf() adds per operand (the scores are finite by construction)
+__device__ __forceinline__ float wb_max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
     extern __shared__ __align__(16) float lds[];
@@ -308,8 +314,8 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
                     float m2 = mx;
 #pragma unroll
                     for (int j = 0; j < HT; ++j) {
-                        m2 = fmaxf(m2, fmaxf(sc[cb][j][0], sc[cb][j][1]));
-                        m2 = fmaxf(m2, fmaxf(sc[cb][j][2], sc[cb][j][3]));
+                        m2 = wb_max3(m2, sc[cb][j][0], sc[cb][j][1]);
+                        m2 = wb_max3(m2, sc[cb][j][2], sc[cb][j][3]);
                     }
                     if (hf == 1) {
                         const float corr = __builtin_amdgcn_exp2f(mx - m2);
