@@ -1135,7 +1135,7 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
     Workspace& ws = m->W();
     const long ev_fs = (long)B * m->cfg.num_bins * H * W, img_fs = (long)B * H * W;
     BDE_TRY(copy_frames(events, ws.ev, T, ev_fs, 0, s));
-    const bool can_graph = m->use_graph && !m->overlap && ws.warm;   // (profiling spans are captured as event-record nodes)
+    const bool can_graph = m->use_graph && !(m->overlap && m->pipeline < 2) && ws.warm;   // (profiling spans are captured as event-record nodes)
     if (can_graph && !ws.graph_exec) {
         // capture on a private stream (the caller's may be the legacy default stream, which cannot
         // capture); the instantiated graph is then launched on the caller's stream
@@ -1208,7 +1208,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         return BDE_OK;
     };
     static auto decode_fn = decode_frames;
-    const bool overlap = m->overlap != 0;
+    const bool overlap = m->overlap != 0 && m->pipeline < 2;   // the side stream and its events are per model, not per slot
     if (overlap && !m->side) {
         int lo = 0, hi = 0;                               // lowest priority: the chain on the main stream goes first
         BDE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
