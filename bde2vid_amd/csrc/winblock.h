@@ -9,7 +9,8 @@
 //            constant W*beta + b by itself (mean 0, variance 0), so no pad vector is needed.
 //   softmax(q k^T + bias) v   per head (DTransformer.py:192-203): one wave per head; the 16 x 16 score tiles
 //            come from one MFMA each (K = head_dim = 4) with the relative-position bias as its C operand,
-//            the exponentials and p*v run on the vector ALU, lane = (query, quarter of the keys)
+//            the exponentials and p*v run on the vector ALU, lane = (query, quarter of the keys); the 49th
+//            query (a tile of its own otherwise) is taken with the keys on the lanes instead
 //   x1 = x + proj(.)          DTransformer.py:204,299
 //   x2 = x1 + fc2(GELU(fc1(LayerNorm2(x1))))   (+ merged[t] after the last block, V5.py:166)
 //
@@ -273,11 +274,12 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
         float ap[16];                          // proj fragments (4 row tiles x 4 token tiles, one per wave)
         {
             const int h = wave;
-            float kf[WB_NT], qf[4];
+            constexpr int NQT = 3;                 // query tiles on the MFMA path: queries 0..47; query 48 below
+            float kf[WB_NT], qf[NQT];
 #pragma unroll
             for (int j = 0; j < WB_NT; ++j) kf[j] = KL[(j * WB_C + h * WB_HD + g4) * 16 + col];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qf[i] = QL[(i * WB_C + h * WB_HD + g4) * 16 + col];
+            for (int i = 0; i < NQT; ++i) qf[i] = QL[(i * WB_C + h * WB_HD + g4) * 16 + col];
             const float* bf = a.biasF + (long)h * 4 * WB_NT * 256 + lane;
             // Half a query tile (5 key tiles = 20 scores per lane) at a time, the bias of the next half in
             // flight meanwhile; every lane keeps its own running maximum over its quarter of the keys and
@@ -288,16 +290,26 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
             for (int j = 0; j < HT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sc[0][j][r] = bf[(j * 4 + r) * 64];
-            const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
-            float pm[4], pl[4], po[4][4];                              // per query tile: max, sum, p*v of this lane's keys
+            // The 49th query would be a tile of its own (a quarter of the softmax work for one token): it is taken
+            // with the KEYS on the lanes instead, lane (col, g4) and register r <-> key 16*col + 4*g4 + r (col < 10).
+            // Its bias values sit in column 0 of query tile 3 of the table.
+            float s48[4];
+            {
+                const int jt = min(col, WB_NT - 1);
+                const float* b48 = a.biasF + ((long)(h * 4 + 3) * WB_NT + jt) * 256 + g4 * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                for (int r = 0; r < 4; ++r) s48[r] = col < WB_NT ? b48[r * 64] : -1e30f;
+            }
+            const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
+            float pm[NQT], pl[NQT], po[NQT][4];                        // per query tile: max, sum, p*v of this lane's keys
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) {
                 float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int cb = hf, nx = hf ^ 1;
                     const int nt = (i * 2 + hf + 1);                     // next half-tile overall
-                    if (nt < 8) {
+                    if (nt < 2 * NQT) {
 #pragma unroll
                         for (int j = 0; j < HT; ++j)
 #pragma unroll
@@ -349,39 +361,75 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
             }
 #pragma unroll
             for (int k4 = 0; k4 < 16; ++k4) ap[k4] = a.wproj[((wave & 3) * 16 + k4) * 64 + lane];
+            // ---- query 48: keys on the lanes ----------------------------------------------------------
+            float l48, o48[4];
+            {
+                const int jt = min(col, WB_NT - 1);
+                float q48[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) q48[c] = QL[(3 * WB_C + h * WB_HD + c) * 16];     // token 48 = tile 3, column 0
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s48[r] += q48[c] * KL[(jt * WB_C + h * WB_HD + c) * 16 + g4 * 4 + r];
+                float m48 = wb_max3(s48[0], s48[1], fmaxf(s48[2], s48[3]));
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) m48 = fmaxf(m48, wb_shfl_xor(m48, sh));
+                l48 = 0.f;
+                o48[0] = o48[1] = o48[2] = o48[3] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(s48[r] - m48);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(VL + (jt * 16 + g4 * 4 + r) * WB_VP + h * WB_HD);
+                    l48 += pr;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o48[c] += pr * v[c];
+                }
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {
+                    l48 += wb_shfl_xor(l48, sh);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o48[c] += wb_shfl_xor(o48[c], sh);
+                }
+            }
             // merge the four key quarters of each query (lanes col, col+16, col+32, col+48)
-            float M[4], f[4];
+            float M[NQT], f[NQT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) M[i] = fmaxf(pm[i], wb_shfl_xor(pm[i], 16));
+            for (int i = 0; i < NQT; ++i) M[i] = fmaxf(pm[i], wb_shfl_xor(pm[i], 16));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) M[i] = fmaxf(M[i], wb_shfl_xor(M[i], 32));
+            for (int i = 0; i < NQT; ++i) M[i] = fmaxf(M[i], wb_shfl_xor(M[i], 32));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NQT; ++i) {
                 f[i] = __builtin_amdgcn_exp2f(pm[i] - M[i]);
                 pl[i] *= f[i];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) po[i][c] *= f[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NQT; ++i) {
                 pl[i] += wb_shfl_xor(pl[i], 16);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) po[i][c] += wb_shfl_xor(po[i][c], 16);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NQT; ++i) {
                 pl[i] += wb_shfl_xor(pl[i], 32);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) po[i][c] += wb_shfl_xor(po[i][c], 32);
             }
             if (lane < 16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NQT; ++i) {
                     const float inv = 1.f / pl[i];
                     float* ao = AO + (i * WB_C + h * WB_HD) * 16 + lane;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) ao[c * 16] = po[i][c] * inv;
                 }
+                // token tile 3: column 0 = query 48, the other columns carry no attention output
+                const float inv48 = 1.f / l48;
+                float* ao3 = AO + (3 * WB_C + h * WB_HD) * 16 + lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ao3[c * 16] = lane == 0 ? o48[c] * inv48 : 0.f;
             }
         }
         wb_sync();
