@@ -108,34 +108,66 @@ static int add2(const float* a, const float* b, float* o, long n, hipStream_t s)
 // Bilinear x2 (align_corners=False) of (a + b): the input of UpsampleConvLayer's conv
 // (submodules.py:138) with the skip_sum (V5.py:289-293) folded in.  src = dst/2 - 0.25 clamped at 0:
 // even dst 2k -> 0.25*in[k-1] + 0.75*in[k]; odd dst 2k+1 -> 0.75*in[k] + 0.25*in[k+1]; edges clamp.
+// One thread = two source columns of one source row -> a 2 x 4 block of outputs (two 16-byte stores); the 3 x 4
+// source neighbourhood is read once (the one-output-per-thread form made 8 scalar loads and two integer
+// divisions per output).  Same expression per output as the reference's bilinear weights.
 __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              float* __restrict__ out, int Hs, int Ws, long planes) {
-    const int Wo = 2 * Ws, Ho = 2 * Hs;
-    const long total = planes * Ho * Wo;
+    const int Wo = 2 * Ws, W2 = (Ws + 1) / 2;            // W2 column pairs per source row
+    const long total = planes * Hs * W2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % Wo);
-        const long t = i / Wo;
-        const int y = (int)(t % Ho);
-        const long pl = t / Ho;
-        int ya = max((y - 1) >> 1, 0), yb = min((y + 1) >> 1, Hs - 1);
-        int xa = max((x - 1) >> 1, 0), xb = min((x + 1) >> 1, Ws - 1);
-        if (y == 0) ya = yb = 0;
-        if (x == 0) xa = xb = 0;
-        float wyb = (y & 1) ? 0.25f : 0.75f, wxb = (x & 1) ? 0.25f : 0.75f;
-        if (ya == yb) wyb = 1.f;
-        if (xa == xb) wxb = 1.f;
-        const float wya = 1.f - wyb, wxa = 1.f - wxb;
+        const int jp = (int)(i % W2);
+        const long t = i / W2;
+        const int k = (int)(t % Hs);
+        const long pl = t / Hs;
+        const int j0 = 2 * jp;
         const float* pa = a + pl * Hs * Ws;
-        float v00 = pa[ya * Ws + xa], v01 = pa[ya * Ws + xb], v10 = pa[yb * Ws + xa], v11 = pa[yb * Ws + xb];
-        if (b) {
-            const float* pb = b + pl * Hs * Ws;
-            v00 += pb[ya * Ws + xa]; v01 += pb[ya * Ws + xb]; v10 += pb[yb * Ws + xa]; v11 += pb[yb * Ws + xb];
+        const float* pb = b ? b + pl * Hs * Ws : nullptr;
+        const int ym = max(k - 1, 0), yp = min(k + 1, Hs - 1);
+        int xc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xc[c] = min(max(j0 - 1 + c, 0), Ws - 1);
+        float v[3][4];
+        const int yr[3] = {ym, k, yp};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = pa[yr[r] * Ws + xc[c]];
+                if (pb) x += pb[yr[r] * Ws + xc[c]];
+                v[r][c] = x;
+            }
+        float* ob = out + pl * 4 * Hs * Ws;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = 2 * k + dy;
+            // rows (ya, yb) and weights exactly as the per-output form: even y -> (k-1, k) with (0.25, 0.75),
+            // odd y -> (k, k+1) with (0.75, 0.25); a clamped pair collapses to weight 1 on one row
+            const int ra = dy == 0 ? 0 : 1, rb = dy == 0 ? 1 : 2;
+            float wyb = dy ? 0.25f : 0.75f;
+            if (yr[ra] == yr[rb]) wyb = 1.f;
+            const float wya = 1.f - wyb;
+            float o[4];
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int x = 2 * j0 + dx;               // output column; source pair (xa, xb) = columns ca, cb of v
+                const int ca = (dx + 1) / 2, cb = ca + 1;   // dx 0: (j0-1, j0); 1: (j0, j0+1); 2: (j0, j0+1); 3: (j0+1, j0+2)
+                float wxb = (x & 1) ? 0.25f : 0.75f;
+                if (xc[ca] == xc[cb]) wxb = 1.f;
+                const float wxa = 1.f - wxb;
+                o[dx] = wya * (wxa * v[ra][ca] + wxb * v[ra][cb]) + wyb * (wxa * v[rb][ca] + wxb * v[rb][cb]);
+            }
+            float* op = ob + (long)y * Wo + 2 * j0;
+            if (j0 + 1 < Ws && (Ws & 1) == 0) *reinterpret_cast<float4*>(op) = float4{o[0], o[1], o[2], o[3]};   // rows 16-byte aligned
+            else {
+                op[0] = o[0]; op[1] = o[1];
+                if (j0 + 1 < Ws) { op[2] = o[2]; op[3] = o[3]; }
+            }
         }
-        out[i] = wya * (wxa * v00 + wxb * v01) + wyb * (wxa * v10 + wxb * v11);
     }
 }
 static int upsample2x_sum(const float* a, const float* b, float* out, int Hs, int Ws, long planes, hipStream_t s) {
-    const long total = planes * 4 * Hs * Ws;
+    const long total = planes * Hs * ((Ws + 1) / 2);
     long blocks = std::min<long>(cdivl(total, 256), 8192);
     hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, Hs, Ws, planes);
     BDE_HIP(hipGetLastError());
