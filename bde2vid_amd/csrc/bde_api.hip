@@ -292,6 +292,41 @@ static PackedLayer pack_lstm16(Arena& ar, const std::vector<const DenseLayer*>& 
     return pl;
 }
 
+// The same weights for 8-channel workgroups (lstm16.h, HC8): [hidden8 block][chunk][tap][k4][64 lanes][tile 2],
+// tile t stacks gates 2t and 2t+1: lane l -> row m = l&15: gate 2t + (m>>3), hidden channel hb*8 + (m&7).
+static PackedLayer pack_lstm8(Arena& ar, const std::vector<const DenseLayer*>& groups) {
+    const DenseLayer& d0 = *groups[0];
+    PackedLayer pl;
+    pl.Cin = d0.Cin;
+    pl.Cout = d0.rows;
+    pl.KS = 3;
+    pl.lstm = true;
+    pl.G = (int)groups.size();
+    pl.CK = L16_CK;
+    pl.nchunks = cdiv(d0.Cin, L16_CK);
+    const int Ch = d0.rows / 4, nhb = cdiv(Ch, 8);
+    pl.ntiles = nhb;
+    const long afl = 9 * 2 * 64 * 2;
+    pl.w_sz = (long)nhb * pl.nchunks * afl;
+    pl.w_off = ar.alloc(pl.w_sz * pl.G);
+    pl.b_off = -1;
+    for (int g = 0; g < pl.G; ++g) {
+        const DenseLayer& d = *groups[g];
+        float* dst = ar.host.data() + pl.w_off + g * pl.w_sz;
+        for (int hb = 0; hb < nhb; ++hb)
+            for (int ch = 0; ch < pl.nchunks; ++ch)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int k4 = 0; k4 < 2; ++k4)
+                        for (int l = 0; l < 64; ++l)
+                            for (int t = 0; t < 2; ++t) {
+                                const int m = l & 15, gate = 2 * t + (m >> 3), hc = hb * 8 + (m & 7), ci = ch * 8 + k4 * 4 + (l >> 4);
+                                const long o = ((((long)(hb * pl.nchunks + ch) * 9 + tap) * 2 + k4) * 64 + l) * 2 + t;
+                                dst[o] = (hc < Ch && ci < d.Cin) ? d.w[((long)(gate * Ch + hc) * d.Cin + ci) * 9 + tap] : 0.f;
+                            }
+    }
+    return pl;
+}
+
 // Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
 // four (one per wave); pointwise layers CK = 16 in groups of eight (any pw_gemm split-K factor).
 static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, bool lstm) {
@@ -381,7 +416,7 @@ struct bde_model {
     float* dev = nullptr;   // device image of the arena
     long dev_numel = 0;
     PackedLayer head, pred_dummy;
-    std::vector<PackedLayer> enc, gx, lstm, dec;   // enc/gx/lstm: G=2 (fwd,bwd)
+    std::vector<PackedLayer> enc, gx, lstm, lstm8, dec;   // enc/gx/lstm: G=2 (fwd,bwd); lstm8 = the 8-channel-workgroup packing
     std::vector<AttnLevel> attn;
     long predw_off = -1, predb_off = -1;
     // Workspace slots: slot 0 always; with pipeline depth 2 consecutive forward calls alternate between
@@ -411,6 +446,7 @@ struct bde_model {
                                   // bit2 recurrent steps, bit3 decoder, bit4 encoder + gate convs
     int tok_debug = 0;
     unsigned long long* tok_stamps = nullptr;
+    int lstm_hc8 = -1;            // recurrent step with 8-channel workgroups: -1 auto (lstm16_wants_hc8), 0 never, 1 always
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
@@ -505,6 +541,7 @@ static int build_packed(bde_model* m) {
     m->enc.assign(L, PackedLayer());
     m->gx.assign(L, PackedLayer());
     m->lstm.assign(L, PackedLayer());
+    m->lstm8.assign(L, PackedLayer());
     m->dec.assign(L, PackedLayer());
     m->attn.assign(L, AttnLevel());
     {
@@ -528,6 +565,7 @@ static int build_packed(bde_model* m) {
         m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, false);
         m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, false);
         m->lstm[l] = pack_lstm16(ar, {&gh[0], &gh[1]});
+        m->lstm8[l] = pack_lstm8(ar, {&gh[0], &gh[1]});
     }
     const int D = c.frame_num, heads = c.num_heads;
     const int tbl_rows = (2 * D - 1) * 13 * 13;
@@ -892,7 +930,12 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         {
             static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
             ProfScope ps(m, names[l], s);
-            BDE_TRY(lstm16_launch(a, s));
+            const bool hc8 = m->lstm_hc8 == 1 || (m->lstm_hc8 < 0 && lstm16_wants_hc8(a));
+            if (hc8) {                                   // 8-channel workgroups: their own weight packing
+                a.wpk = m->P(m->lstm8[l].w_off);
+                a.w_gs = m->lstm8[l].w_sz;
+            }
+            BDE_TRY(lstm16_launch(a, s, hc8));
         }
     }
     return BDE_OK;
@@ -1453,6 +1496,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     for (auto& w : m->wslots)
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
     if (std::string(key) == "attn_mfma") { attn_mfma_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_hc8") { m->lstm_hc8 = (int)value; return BDE_OK; }
     if (std::string(key) == "winblock") { m->winblock = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { pw_batched_ref() = (int)value; return BDE_OK; }
@@ -1486,9 +1530,9 @@ int bde_debug_occupancy(const char* kernel) {
     int nb = -1;
     std::string k(kernel ? kernel : "");
     hipError_t e = hipErrorInvalidValue;
-    if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 1>, 256, 0);
-    else if (k == "lstm16_1_128_s2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 128, 2>, 256, 0);
-    else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32, 1>, 256, 0);
+    if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 1, false>, 256, 0);
+    else if (k == "lstm16_1_128_s2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 128, 2, false>, 256, 0);
+    else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32, 1, false>, 256, 0);
     else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64));
     else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, conv_maxi(3)>, 256, 42 * 1024);
     if (e != hipSuccess) return -1;

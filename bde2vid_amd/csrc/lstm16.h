@@ -52,10 +52,17 @@ constexpr int l16_iwp(int rows, int pxw) {
 // The halo tile is staged row-wise: a pass of all threads copies NT/PXW tile rows of PXW floats
 // (coalesced, LDS address affine in the pass number), one more pass the two right-hand halo columns.
 // Uses the ConvArgs fields of EPI_LSTM (in = h_prev, out = h, gx, cstate, first, strides).
-template <int ROWS, int PXW, int SEG>
+// HC8: a workgroup owns 8 hidden channels instead of 16; an MFMA tile then stacks two gates (rows 0-7 gate a,
+// rows 8-15 gate b of the same 8 channels), two tiles (i|f, o|g) per k-step instead of four.  Waves of half the
+// size: a level whose 16-channel launch leaves a CU with one or two workgroups (level 2 of config A: 384 on 256
+// CUs, the busiest SIMD carrying two 74 k-cycle waves) becomes 768 workgroups = three 37 k-cycle waves per SIMD.
+template <int ROWS, int PXW, int SEG, bool HC8>
 __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_per_eu(SEG == 1 ? 4 : 3, 8))) void lstm16_step_kernel(const ConvArgs a) {
+    static_assert(!HC8 || SEG == 1, "8-channel workgroups are built for one-segment waves");
+    constexpr int NG = HC8 ? 2 : 4;                  // MFMA tiles per k-step
+    constexpr int AFL = 9 * 2 * 64 * NG;             // floats of one stage's weight fragments
     constexpr int NT = ROWS * PXW * 4 / SEG;         // threads per workgroup (64 per wave)
-    constexpr int AFL4 = L16_AFL / 4;                // float4 of one stage's weight fragments
+    constexpr int AFL4 = AFL / 4;                    // float4 of one stage's weight fragments
     constexpr int AK4 = (AFL4 + NT - 1) / NT;        // 16-byte weight loads per thread and stage
     constexpr int R = ROWS + 2;
     constexpr int IWP = l16_iwp(ROWS, PXW);
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
     constexpr int NPASS = NR / RPP;
     static_assert(NR % RPP == 0 && NT % PXW == 0 && 2 * NR <= NT, "halo staging shape");
     constexpr int XT = PXW / (16 * SEG);             // waves along x
-    __shared__ __align__(16) float ldsA[L16_AFL];
+    __shared__ __align__(16) float ldsA[AFL];
     __shared__ __align__(16) float ldsB[L16_CK * PLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.z;
@@ -74,20 +81,25 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
     const int tiles_x = (W + PXW - 1) / PXW;
     const int ty = blockIdx.x / tiles_x;
     const int y0 = ty * ROWS, x0 = (blockIdx.x - ty * tiles_x) * PXW;
-    const int hb = blockIdx.y;                               // hidden16 block of this workgroup
+    const int hb = blockIdx.y;                               // hidden-channel block (HCB channels) of this workgroup
     const int wrow = wave / XT, wx = wave - wrow * XT;       // this wave's row and first 16-pixel segment
     const int pxl = wx * 16 * SEG + (lane & 15);             // x of this lane (segment 0) inside the tile
     const int y = y0 + wrow;
     const bool wave_active = (x0 + wx * 16 * SEG) < W && y < H;
 
-    f32x4_ acc[SEG][4];
+    f32x4_ acc[SEG][NG];
 #pragma unroll
     for (int sg = 0; sg < SEG; ++sg)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[sg][q] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NG; ++q) acc[sg][q] = f32x4_{0.f, 0.f, 0.f, 0.f};
 
-    // gx / c_prev of this lane's (pixel, 4 hidden channels) x SEG, fetched during the last stage
-    float gv[SEG][4][4], cprev[SEG][4];
+    // gx / c_prev of this lane's (pixel, hidden channels) x SEG, fetched during the last stage.  16-channel
+    // workgroups: the lane finishes channels hb*16 + 4*g4 + r, r < 4; 8-channel ones: hb*8 + 4*(g4&1) + r0 + e,
+    // e < 2 with r0 = 0 on the lanes holding the first gate of a pair (g4 < 2) and 2 on the others.
+    constexpr int NE = HC8 ? 2 : 4;
+    const int g4 = lane >> 4;
+    const int hc0 = HC8 ? hb * 8 + 4 * (g4 & 1) + (g4 < 2 ? 0 : 2) : hb * 16 + g4 * 4;
+    float gv[SEG][4][NE], cprev[SEG][NE];
     const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
     float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
     auto epi_load = [&]() {
@@ -95,8 +107,8 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
         for (int sg = 0; sg < SEG; ++sg) {
             const unsigned p = (unsigned)(min(y, H - 1) * W + min(x0 + pxl + sg * 16, W - 1));   // clamped: in bounds
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned hc = (unsigned)min(hb * 16 + (lane >> 4) * 4 + r, Ch - 1);
+            for (int r = 0; r < NE; ++r) {
+                const unsigned hc = (unsigned)min(hc0 + r, Ch - 1);
                 const unsigned o = hc * (unsigned)HW + p;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) gv[sg][q][r] = gxb[(unsigned)(q * Ch) * (unsigned)HW + o];
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
     if (a.first) epi_load();
     if (!a.first) {
         const float* inb = a.in + g * a.in_gs + n * a.in_ns;
-        const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + g * a.w_gs + (long)hb * a.nchunks * L16_AFL);
+        const float4* wsrc = reinterpret_cast<const float4*>(a.wpk + g * a.w_gs + (long)hb * a.nchunks * AFL);
         // halo staging slots of this thread
         const int sub = tid / PXW, col = tid - sub * PXW;
         const int ixm = x0 - 1 + col;
@@ -160,16 +172,22 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
             // Fragment reads run one tap ahead of the MFMAs (two register sets): a wave alone on its SIMD
             // otherwise idles the matrix pipe for an LDS round trip after every tap, and the waves of a
             // launch move through their stages too much in step to cover that for each other.
-            float bq[2][2][SEG], aq[2][2][4];
+            float bq[2][2][SEG], aq[2][2][NG];
             auto frag_read = [&](int tap, int buf) {
                 const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
                 for (int k4 = 0; k4 < 2; ++k4) {
 #pragma unroll
                     for (int sg = 0; sg < SEG; ++sg) bq[buf][k4][sg] = ldsB[bofl + k4 * 4 * PLS + ky * IWP + kx + sg * 16];
-                    const f32x4_ av = *reinterpret_cast<const f32x4_*>(ldsA + ((tap * 2 + k4) * 64 + lane) * 4);
+                    if constexpr (HC8) {
+                        const float2 av = *reinterpret_cast<const float2*>(ldsA + ((tap * 2 + k4) * 64 + lane) * 2);
+                        aq[buf][k4][0] = av.x;
+                        aq[buf][k4][1] = av.y;
+                    } else {
+                        const f32x4_ av = *reinterpret_cast<const f32x4_*>(ldsA + ((tap * 2 + k4) * 64 + lane) * 4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) aq[buf][k4][q] = av[q];
+                        for (int q = 0; q < 4; ++q) aq[buf][k4][q] = av[q];
+                    }
                 }
             };
             frag_read(0, 0);
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
 #pragma unroll
                     for (int sg = 0; sg < SEG; ++sg)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < NG; ++q)
                             acc[sg][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[buf][k4][q], bq[buf][k4][sg], acc[sg][q], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -206,36 +224,56 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
 #pragma unroll
     for (int sg = 0; sg < SEG; ++sg) {
         const int x = x0 + pxl + sg * 16;
+        float gi[NE], gf[NE], go[NE], gg[NE];
+        if constexpr (HC8) {
+            // tile 0 = i | f, tile 1 = o | g: this lane holds one gate of each pair for channels 4*(g4&1) + r,
+            // lane ^ 32 the other one; each of the two finishes two of the four channels
+            const bool lo = g4 < 2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float own0 = lo ? acc[sg][0][e] : acc[sg][0][2 + e], own1 = lo ? acc[sg][1][e] : acc[sg][1][2 + e];
+                // the partner needs this lane's values of ITS two channels (the other pair of registers)
+                const float snd0 = lo ? acc[sg][0][2 + e] : acc[sg][0][e], snd1 = lo ? acc[sg][1][2 + e] : acc[sg][1][e];
+                const float oth0 = __shfl_xor(snd0, 32), oth1 = __shfl_xor(snd1, 32);
+                gi[e] = lo ? own0 : oth0;
+                gf[e] = lo ? oth0 : own0;
+                go[e] = lo ? own1 : oth1;
+                gg[e] = lo ? oth1 : own1;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { gi[r] = acc[sg][0][r]; gf[r] = acc[sg][1][r]; go[r] = acc[sg][2][r]; gg[r] = acc[sg][3][r]; }
+        }
         if (x >= W) continue;
         const long p = (long)y * W + x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int hc = hb * 16 + (lane >> 4) * 4 + r;
+        for (int r = 0; r < NE; ++r) {
+            const int hc = hc0 + r;
             if (hc >= Ch) continue;
             const long o = (long)hc * HW + p;
-            const float gi = acc[sg][0][r] + gv[sg][0][r], gf = acc[sg][1][r] + gv[sg][1][r];
-            const float go = acc[sg][2][r] + gv[sg][2][r], gg = acc[sg][3][r] + gv[sg][3][r];
-            const float c = sigmoid_fast(gf) * cprev[sg][r] + sigmoid_fast(gi) * tanh_fast(gg);
+            const float vi = gi[r] + gv[sg][0][r], vf = gf[r] + gv[sg][1][r];
+            const float vo = go[r] + gv[sg][2][r], vg = gg[r] + gv[sg][3][r];
+            const float c = sigmoid_fast(vf) * cprev[sg][r] + sigmoid_fast(vi) * tanh_fast(vg);
             cst[o] = c;
-            hout[o] = sigmoid_fast(go) * tanh_fast(c);
+            hout[o] = sigmoid_fast(vo) * tanh_fast(c);
         }
     }
 }
 
 inline int& lstm16_shape_ref() { static int v = 0; return v; }    // tuning: seg*100000 + rows*1000 + pxw, 0 = auto
 
-template <int ROWS, int PXW, int SEG>
+template <int ROWS, int PXW, int SEG, bool HC8>
 static int lstm16_launch_t(const ConvArgs& a, hipStream_t stream) {
     const int Ch = a.Cout / 4;
-    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, 16), 2 * a.N);
-    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW, SEG>), grid, dim3(ROWS * PXW * 4 / SEG), 0, stream, a);
+    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, HC8 ? 8 : 16), 2 * a.N);
+    hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW, SEG, HC8>), grid, dim3(ROWS * PXW * 4 / SEG), 0, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 
-static int lstm16_launch(const ConvArgs& a, hipStream_t stream) {
-    if (a.Cin % L16_CK != 0) return fail(BDE_ERR_UNSUPPORTED, "recurrent step: %d hidden channels is not a multiple of %d", a.Cin, L16_CK);
-    // tile shape with the most active 16-pixel wave segments per launched wave
+// 16-channel launch geometry of a step: shape and workgroup count (the host picks the 8-channel weights and
+// kernel from it)
+static void lstm16_geometry(const ConvArgs& a, int* rows_, int* pxw_, int* seg_, long* wg16_) {
     auto fill = [&](int rows, int pxw) {
         const double segs = (double)a.Ho * cdiv(a.Wo, 16);
         return segs / ((double)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * (rows * pxw / 16));
@@ -247,13 +285,31 @@ static int lstm16_launch(const ConvArgs& a, hipStream_t stream) {
     // more one-segment workgroups than the chip holds at once (4 per CU): two segments per wave
     const long wg1 = (long)cdiv(a.Ho, rows) * cdiv(a.Wo, pxw) * cdiv(a.Cout / 4, 16) * 2 * a.N;
     if (wg1 > 1024 && fill(1, 128) >= bf - 0.08) { rows = 1; pxw = 128; seg = 2; }
-    if (const int f = lstm16_shape_ref()) { seg = f / 100000; rows = (f / 1000) % 100; pxw = f % 1000; }
-#define BDE_L16(R_, P_, S_) if (rows == R_ && pxw == P_ && seg == S_) return lstm16_launch_t<R_, P_, S_>(a, stream);
-    BDE_L16(1, 64, 1)
-    BDE_L16(2, 32, 1)
-    BDE_L16(4, 16, 1)
-    BDE_L16(1, 128, 2)
+    *rows_ = rows; *pxw_ = pxw; *seg_ = seg; *wg16_ = wg1;
+}
+
+// 8-channel workgroups pay off when the 16-channel launch cannot give every CU the same number of workgroups
+// and is small enough that doubling the count still fits the chip at once
+static bool lstm16_wants_hc8(const ConvArgs& a) {
+    int rows, pxw, seg; long wg16;
+    lstm16_geometry(a, &rows, &pxw, &seg, &wg16);
+    return seg == 1 && wg16 < 640 && wg16 % 256 != 0 && (a.Cout / 4) % 8 == 0;
+}
+
+static int lstm16_launch(const ConvArgs& a, hipStream_t stream, bool hc8 = false) {
+    if (a.Cin % L16_CK != 0) return fail(BDE_ERR_UNSUPPORTED, "recurrent step: %d hidden channels is not a multiple of %d", a.Cin, L16_CK);
+    int rows, pxw, seg;
+    long wg16;
+    lstm16_geometry(a, &rows, &pxw, &seg, &wg16);
+    if (const int f = lstm16_shape_ref()) { seg = (f / 100000) % 100; rows = (f / 1000) % 100; pxw = f % 1000; }
+    if (hc8 && seg != 1) return fail(BDE_ERR_ARG, "recurrent step: 8-channel workgroups need one-segment waves");
+#define BDE_L16(R_, P_) \
+    if (rows == R_ && pxw == P_ && seg == 1) return hc8 ? lstm16_launch_t<R_, P_, 1, true>(a, stream) : lstm16_launch_t<R_, P_, 1, false>(a, stream);
+    BDE_L16(1, 64)
+    BDE_L16(2, 32)
+    BDE_L16(4, 16)
 #undef BDE_L16
+    if (rows == 1 && pxw == 128 && seg == 2) return lstm16_launch_t<1, 128, 2, false>(a, stream);
     return fail(BDE_ERR_ARG, "recurrent step: tile shape %dx%d (x%d segments) not built", rows, pxw, seg);
 }
 

@@ -20,6 +20,8 @@ if os.environ.get('LSTM_SHAPE'):
     m.set_tuning('lstm_shape', int(os.environ['LSTM_SHAPE']))
 if os.environ.get('CONV_NT'):
     m.set_tuning('conv_nt', int(os.environ['CONV_NT']))
+if os.environ.get('LSTM_HC8'):
+    m.set_tuning('lstm_hc8', int(os.environ['LSTM_HC8']))
 if os.environ.get('TOK_NPT'):
     m.set_tuning('tok_npt', int(os.environ['TOK_NPT']))
 if os.environ.get('TOK_DEBUG'):
