@@ -804,6 +804,8 @@ static int ws_alloc(Workspace& ws, float** p, long numel) {
     return BDE_OK;
 }
 
+static bool winblock_ok(const bde_model* m, int l);
+
 static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     Workspace& ws = m->W();
     if (ws.T == T && ws.B == B && ws.H == H && ws.W == W) return BDE_OK;
@@ -825,10 +827,15 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.cst[l], 2 * (long)B * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.merged[l], TB * C * hw));
         if (c.depths[l] > 0) {
-            BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
-            BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
-            BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
-            BDE_TRY(ws_alloc(ws, &ws.mergedT[l], TB * C * hw));   // token-major twin of merged (winblock.h)
+            if (winblock_ok(m, l)) {
+                // one-launch blocks recompute the neighbours' K|V: only the token-major twin of merged is staged
+                // (the K|V stacks of the split path are 71 GB at 1280x720, T = 64)
+                BDE_TRY(ws_alloc(ws, &ws.mergedT[l], TB * C * hw));
+            } else {
+                BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
+                BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
+                BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
+            }
             max_attn = std::max(max_attn, (long)B * C * hw);
         }
         const int j = L - 1 - l;   // decoder j writes the map of level (L-1-j)'s input resolution
@@ -1497,7 +1504,12 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
     if (std::string(key) == "attn_mfma") { attn_mfma_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_hc8") { m->lstm_hc8 = (int)value; return BDE_OK; }
-    if (std::string(key) == "winblock") { m->winblock = (int)value; return BDE_OK; }
+    if (std::string(key) == "winblock") {
+        if (m->winblock != (int)value)
+            for (auto& w : m->wslots) w.release();           // the two paths stage different buffers
+        m->winblock = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { pw_batched_ref() = (int)value; return BDE_OK; }
     if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
