@@ -1207,7 +1207,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
 
 // Everything between the input copy and the output copy: pointers depend only on the workspace,
 // so the launch sequence can be captured once per (slot, T, B, H, W) into a hipGraph and replayed
-// (~1300 launches per forward at config A; replay removes their host cost).
+// (~630 launches per forward at config A; replay removes their host cost).
 static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s);
 
 static int forward_on(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
