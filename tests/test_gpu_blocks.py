@@ -200,3 +200,19 @@ def test_voxel_windows_from_native_columns(name, case):
     bad[5] = W
     with pytest.raises(IndexError):
         events_to_voxel_windows(bad, ys, ts, ps, idx, 5, sensor_size=(H, W))
+
+
+@pytest.mark.parametrize('hc8', [0, 1])
+def test_recurrent_step_workgroup_variants(blocks, hc8):
+    """The recurrent step with 16-channel workgroups and with 8-channel ones (two gates stacked per MFMA tile,
+    csrc/lstm16.h) against the same goldens; the library picks between them per level by launch geometry."""
+    from bde2vid_amd import ops
+    z, cfg, sd, m = blocks
+    x = dev(np.stack([dense_like((1, 16, 24, 32), 20 + t) for t in range(3)]))
+    m.set_tuning('lstm_hc8', hc8)
+    try:
+        h, c = ops.recurrent_conv(m, 0, 0, x)
+    finally:
+        m.set_tuning('lstm_hc8', -1)
+    assert maxabs(h, z['rc_h']) <= TOL
+    assert maxabs(c, z['rc_c']) <= TOL

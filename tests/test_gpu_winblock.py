@@ -117,3 +117,25 @@ def test_level2_matrix_core_attention_vs_oracle(model_a, shape):
     assert maxabs(y, y_valu.cpu()) <= TOL
     ref0 = oracle_blocks(cfg, sd, [None, bufs[1], None], 0, 2, level=2)
     assert maxabs(ops.dframe_attention(m, 2, [None, dev[1], None], 0, 2), ref0) <= TOL
+
+
+def test_random_shapes_vs_oracle(model_a):
+    """Seeded sweep over map sizes / batch / missing frames: every padding split (0..6 extra rows and columns,
+    odd and even), carried-pixel counts on both sides of the 15-per-window limit, both fallbacks."""
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    rng = np.random.default_rng(20251004)
+    for case in range(10):
+        H, W = int(rng.integers(7, 45)), int(rng.integers(7, 45))
+        B = int(rng.integers(1, 4))
+        bufs = [torch.from_numpy(dense_like((B, 64, H, W), 500 + 10 * case + d)) for d in range(3)]
+        drop = int(rng.integers(0, 4))                       # 0: none, 1: previous, 2: next, 3: both
+        if drop in (1, 3):
+            bufs[0] = None
+        if drop in (2, 3):
+            bufs[2] = None
+        first = int(rng.integers(0, 3))
+        n = int(rng.integers(1, cfg.depths[0] - first + 1))
+        ref = oracle_blocks(cfg, sd, bufs, first, n)
+        y = ops.dframe_attention(m, 0, [None if b is None else b.cuda() for b in bufs], first, n)
+        assert maxabs(y, ref) <= TOL, f'case {case}: {B}x64x{H}x{W}, blocks {first}..{first + n - 1}, drop {drop}'
