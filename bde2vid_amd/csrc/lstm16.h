@@ -169,9 +169,8 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
             __syncthreads();
         };
         auto stage_mfma = [&]() {
-            // Fragment reads run one tap ahead of the MFMAs (two register sets): a wave alone on its SIMD
-            // otherwise idles the matrix pipe for an LDS round trip after every tap, and the waves of a
-            // launch move through their stages too much in step to cover that for each other.
+            // Fragment reads are written one tap ahead of the MFMAs (two register sets); their final interleaving
+            // is left to the compiler's iglp_opt strategies.
             float bq[2][2][SEG], aq[2][2][NG];
             auto frag_read = [&](int tap, int buf) {
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -193,9 +192,11 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
             frag_read(0, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
+                // the compiler's MFMA/DS interleaving (iglp_opt) measured ahead of pinning the reads with
+                // sched_barrier(0): two-segment shape -7 % with strategy 0, 8-channel shape -3 % with strategy 1
+                __builtin_amdgcn_iglp_opt(SEG == 2 ? 0 : 1);
                 const int buf = tap & 1;
                 if (tap + 1 < 9) frag_read(tap + 1, buf ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k4 = 0; k4 < 2; ++k4)
 #pragma unroll
@@ -203,7 +204,6 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
 #pragma unroll
                         for (int q = 0; q < NG; ++q)
                             acc[sg][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[buf][k4][q], bq[buf][k4][sg], acc[sg][q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
         };
         stage_load(0);
