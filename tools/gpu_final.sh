@@ -16,7 +16,7 @@ for mode in default pipeline1; do
 done
 cd $R
 # HBM traffic of the recurrent step kernel: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, rocprofv3 PMC slots)
-tools/gpu_pmc.sh ${TAG}_fetch lstm0 "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum" > gpurun_out/${TAG}_pmc_fetch.txt 2>&1
+tools/gpu_pmc.sh ${TAG}_fetch lstm0 "FETCH_SIZE" > gpurun_out/${TAG}_pmc_fetch.txt 2>&1   # (FETCH_SIZE takes 3 of the 4 TCC slots: alone)
 tools/gpu_pmc.sh ${TAG}_write lstm0 "WRITE_SIZE" > gpurun_out/${TAG}_pmc_write.txt 2>&1
 tools/gpu_pmc.sh ${TAG}_sq lstm0 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" > gpurun_out/${TAG}_pmc_sq.txt 2>&1
 grep -A4 "lstm16" gpurun_out/${TAG}_pmc_fetch.txt | head -8; grep -A2 "lstm16" gpurun_out/${TAG}_pmc_write.txt | head -4
