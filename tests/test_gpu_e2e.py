@@ -204,3 +204,21 @@ def test_example_recording_to_frames(monkeypatch):
     out = mod.main()
     assert tuple(out.shape) == (6, 1, 60, 72)
     assert torch.isfinite(out).all() and float(out.min()) > 0.0 and float(out.max()) < 1.0
+
+
+def test_long_sequence_more_frames_than_one_pointer_block():
+    """T = 70 > 64: the frame gather / scatter launches take the frame pointers 64 at a time; outputs against the oracle."""
+    from oracle import bde2vid_oracle as O
+    z, meta = load_golden('e2e_tiny')
+    from bde2vid_amd.model import build_model
+    cfg, sd, xs = case_from_meta(meta)
+    rng = np.random.default_rng(5)
+    B, C, H, W = xs[0].shape
+    frames = [(rng.standard_normal((B, C, H, W)).astype(np.float32) * 0.5 * (rng.random((B, C, H, W)) > 0.7)).astype(np.float32)
+              for _ in range(70)]
+    m = build_model(cfg, sd, 'cuda:0')
+    with torch.no_grad():
+        ys = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in frames]))
+        ref = torch.stack(O.forward(sd, cfg, [{'events': torch.from_numpy(x)} for x in frames]))
+    assert tuple(ys.shape) == tuple(ref.shape)
+    assert maxabs(ys, ref) <= TOL
