@@ -40,6 +40,7 @@ SIGNATURES = {
     'bde_get_intermediate': (_I, [_P, C.c_char_p, _P, _L, _P]),
     'bde_set_tuning': (_I, [_P, C.c_char_p, _L]),
     'bde_wait_outputs': (_I, [_P, _P]),
+    'bde_get_info': (_I, [_P, C.c_char_p, C.POINTER(_L)]),
     'bde_debug_occupancy': (_I, [C.c_char_p]),
     'bde_debug_token_stamps': (_I, [_P, C.POINTER(_L), _I]),
     'bde_profile_reset': (_I, [_P, _I]),

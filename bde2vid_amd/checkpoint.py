@@ -97,13 +97,27 @@ def generator_config_from_cfg(cfg_source: str) -> GeneratorConfig:
     return cfg
 
 
-def load_model(checkpointfile: str, device='cuda', cpu_cache_length: Optional[int] = None):
+def read_checkpoint(checkpointfile: str, trust_checkpoint: bool = False):
+    """torch.load restricted to tensors and plain containers (`weights_only=True`): nothing in the file is executed.
+    A file that needs the full unpickler (custom classes, e.g. an mmengine object saved into `meta`) is refused
+    unless the caller states that it trusts the file -- unpickling can run arbitrary code."""
+    if trust_checkpoint:
+        return torch.load(checkpointfile, map_location='cpu', weights_only=False)
+    try:
+        return torch.load(checkpointfile, map_location='cpu', weights_only=True)
+    except FileNotFoundError:
+        raise
+    except Exception as e:
+        raise RuntimeError(
+            f'{checkpointfile}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}). '
+            'If the file comes from a source you trust, pass trust_checkpoint=True to use the full unpickler.') from e
+
+
+def load_model(checkpointfile: str, device='cuda', cpu_cache_length: Optional[int] = None,
+               trust_checkpoint: bool = False):
     """Counterpart of `load_model` (`eval_models_seq.py:41-96`) for BDE2VID checkpoints."""
     from .model import BDE2VID
-    try:
-        ckpt = torch.load(checkpointfile, map_location='cpu', weights_only=True)
-    except Exception:
-        ckpt = torch.load(checkpointfile, map_location='cpu', weights_only=False)
+    ckpt = read_checkpoint(checkpointfile, trust_checkpoint)
     if isinstance(ckpt, dict) and 'state_dict' in ckpt:
         sd = ckpt['state_dict']
         meta = ckpt.get('meta') or {}

@@ -194,11 +194,10 @@ static inline int attn_launch(AttnArgs a, int B, hipStream_t stream) {
     case HDV: {                                                                                       \
         auto kern = attn_core_kernel<HDV>;                                                            \
         if (lds > 64 * 1024) {                                                                        \
-            static bool raised = false;                                                               \
-            if (!raised) {                                                                            \
+            static unsigned char raised[BDE_MAX_DEVICES];                                                               \
+            if (first_use_on_device(raised)) {                                                                            \
                 BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                             160 * 1024));                                             \
-                raised = true;                                                                        \
             }                                                                                         \
         }                                                                                             \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                        \

@@ -141,8 +141,6 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(const AttnArgs a) {
     }
 }
 
-inline int& attn_mfma_ref() { static int v = 1; return v; }   // tuning: 0 = attn.h for every head_dim
-
 static inline int attn_mfma16_launch(AttnArgs a, int B, hipStream_t stream) {
     const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
     hipLaunchKernelGGL(attn_mfma16_kernel, dim3(nW, a.heads, B), dim3(256), 0, stream, a);

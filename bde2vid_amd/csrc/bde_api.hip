@@ -432,6 +432,7 @@ struct bde_model {
     hipStream_t pstream[MAX_SLOTS] = {};
     hipEvent_t pin[MAX_SLOTS] = {}, pout[MAX_SLOTS] = {};
     bool pbusy[MAX_SLOTS] = {};
+    hipStream_t last_stream = nullptr;
     long ncalls = 0;
     int device = 0;
     // optional HIP-event timing of tagged launches / stages (bde_profile_*)
@@ -446,6 +447,7 @@ struct bde_model {
                                   // bit2 recurrent steps, bit3 decoder, bit4 encoder + gate convs
     int tok_debug = 0;
     unsigned long long* tok_stamps = nullptr;
+    Tuning tune;                  // launch-shape overrides (common.h), per model
     int lstm_hc8 = -1;            // recurrent step with 8-channel workgroups: -1 auto (lstm16_wants_hc8), 0 never, 1 always
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
@@ -708,6 +710,8 @@ static int build_packed(bde_model* m) {
 }
 
 static int upload(bde_model* m) {
+    // captured graphs hold pointers into the old packed image: drop them (and the workspaces) with it
+    for (auto& w : m->wslots) w.release();
     if (m->dev) (void)hipFree(m->dev);
     m->dev = nullptr;
     m->dev_numel = (long)m->arena.host.size();
@@ -999,7 +1003,7 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
         a.out_bs = C * HW;
         a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
         a.pt = pt; a.pl = plft; a.nWw = Wp / 7; a.dilated = dil ? 1 : 0;
-        if (C / c.num_heads == 16 && D * ATT_TOK <= 160 && attn_mfma_ref()) BDE_TRY(attn_mfma16_launch(a, B, s));
+        if (C / c.num_heads == 16 && D * ATT_TOK <= 160 && tuning().attn_mfma) BDE_TRY(attn_mfma16_launch(a, B, s));
         else BDE_TRY(attn_launch(a, B, s));
         float* dst = last ? out : (x == ws.xa ? ws.xb : ws.xa);
         if (fused) {
@@ -1198,6 +1202,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     m->cur = slot;
     BDE_HIP(hipEventRecord(m->pin[slot], user));
     BDE_HIP(hipStreamWaitEvent(m->pstream[slot], m->pin[slot], 0));
+    m->last_stream = m->pstream[slot];
     const int st = forward_on(m, events, T, B, H, W, images, m->pstream[slot]);
     BDE_HIP(hipEventRecord(m->pout[slot], m->pstream[slot]));
     m->pbusy[slot] = true;
@@ -1479,6 +1484,7 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
                 float* const* images, void* stream) {
     BDE_REQUIRE(m && events && images, "null argument");
     for (int t = 0; t < T; ++t) BDE_REQUIRE(events[t] && images[t], "null frame pointer at t=%d", t);
+    TuningScope ts(&m->tune);
     return forward_impl(m, events, T, B, Hp, Wp, images, (hipStream_t)stream);
 }
 
@@ -1502,7 +1508,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     }
     for (auto& w : m->wslots)
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
-    if (std::string(key) == "attn_mfma") { attn_mfma_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "attn_mfma") { m->tune.attn_mfma = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_hc8") { m->lstm_hc8 = (int)value; return BDE_OK; }
     if (std::string(key) == "winblock") {
         if (m->winblock != (int)value)
@@ -1511,17 +1517,34 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
-    if (std::string(key) == "pw_batched") { pw_batched_ref() = (int)value; return BDE_OK; }
-    if (std::string(key) == "pw_force") { pw_force_ref() = (int)value; return BDE_OK; }
-    if (std::string(key) == "conv_nt") { conv_vec_nt_ref() = (int)value; return BDE_OK; }
-    if (std::string(key) == "conv_vec") { conv_vec_enable_ref() = (int)value; return BDE_OK; }
-    if (std::string(key) == "lstm_shape") { lstm16_shape_ref() = (int)value; return BDE_OK; }
-    if (std::string(key) == "tok_npt") { tok_npt_ref() = (int)value; return BDE_OK; }
+    if (std::string(key) == "pw_batched") { m->tune.pw_batched = (int)value; return BDE_OK; }
+    if (std::string(key) == "pw_force") { m->tune.pw_force = (int)value; return BDE_OK; }
+    if (std::string(key) == "conv_nt") { m->tune.conv_nt = (int)value; return BDE_OK; }
+    if (std::string(key) == "conv_vec") { m->tune.conv_vec = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_shape") { m->tune.lstm_shape = (int)value; return BDE_OK; }
+    if (std::string(key) == "tok_npt") { m->tune.tok_npt = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_debug") { m->tok_debug = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap") { m->overlap = (int)value; return BDE_OK; }
     if (std::string(key) == "debug_skip") { m->debug_skip = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap_chunk") { m->overlap_chunk = std::max<int>(1, (int)value); return BDE_OK; }
     return fail(BDE_ERR_ARG, "unknown tuning key '%s'", key);
+}
+
+int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
+    BDE_REQUIRE(m && key && value, "null argument");
+    const std::string k(key);
+    if (k == "debug_skip") *value = m->debug_skip;                 // != 0: stages are skipped, results are invalid
+    else if (k == "graph") *value = m->use_graph;                  // 0 after a failed capture as well
+    else if (k == "graphs_live") {                                 // workspaces replaying a captured launch sequence
+        int64_t n = 0;
+        for (const auto& w : m->wslots) n += w.graph_exec != nullptr;
+        *value = n;
+    } else if (k == "pipeline") *value = m->pipeline;
+    else if (k == "device") *value = m->device;
+    else if (k == "winblock") *value = m->winblock;
+    else if (k == "packed_numel") *value = m->dev_numel;
+    else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
+    return BDE_OK;
 }
 
 int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n) {
@@ -1638,6 +1661,7 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
 // ---- single sub-modules ----------------------------------------------------------------------
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out, "bad argument");
+    TuningScope ts(&m->tune);
     ConvCall c;
     c.pl = &m->head; c.in = in; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.act = ACT_RELU;
     return run_conv(m, c, (hipStream_t)stream);
@@ -1646,6 +1670,7 @@ int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, 
 int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t N, int32_t H, int32_t W,
                         float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out && level >= 0 && level < m->L && (dir == 0 || dir == 1), "bad argument");
+    TuningScope ts(&m->tune);
     PackedLayer pl = m->enc[level];   // view of a single direction
     pl.G = 1;
     pl.w_off += dir * pl.w_sz;
@@ -1658,6 +1683,7 @@ int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* i
 int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t T, int32_t B, int32_t H,
                           int32_t W, float* h_out, float* c_out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && h_out && level >= 0 && level < m->L && (dir == 0 || dir == 1), "bad argument");
+    TuningScope ts(&m->tune);
     BDE_REQUIRE(H % 2 == 0 && W % 2 == 0, "H, W must be even");
     hipStream_t s = (hipStream_t)stream;
     // run the level on a private workspace sized for this call (full resolution = H << level)
@@ -1677,6 +1703,7 @@ int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float*
 int bde_op_decoder(bde_model* m, int32_t j, const float* in, const float* skip, int32_t N, int32_t H, int32_t W,
                    float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out && j >= 0 && j < m->L, "bad argument");
+    TuningScope ts(&m->tune);
     const int L = m->L, l = L - 1 - j;
     BDE_TRY(ensure_workspace(m, N, 1, H << (l + 1), W << (l + 1)));
     return run_decoder(m, j, in, skip, out, N, H, W, (hipStream_t)stream);
@@ -1697,6 +1724,7 @@ int bde_op_pred(bde_model* m, const float* in, const float* head, int32_t N, int
 int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* bufs, int32_t B, int32_t H, int32_t W,
                             int32_t first_block, int32_t nblocks, float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && bufs && out && level >= 0 && level < m->L, "bad argument");
+    TuningScope ts(&m->tune);
     const AttnLevel& al = m->attn[level];
     BDE_REQUIRE(al.depth > 0, "level %d has no attention", level);
     BDE_REQUIRE(H >= 7 && W >= 7, "map %dx%d smaller than the window", H, W);

@@ -33,6 +33,41 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::bde::fail(BDE_ERR_ARG, __VA_ARGS__);                      \
     } while (0)
 
+// Launch-shape overrides of one model (bde_set_tuning).  The launch helpers in the kernel headers read them through
+// a thread-local pointer that every C-ABI entry point sets to ITS model for the duration of the call, so two models
+// (or two devices) in one process do not see each other's settings.
+struct Tuning {
+    int attn_mfma = 1;      // 0 = attn.h for every head_dim
+    int conv_nt = 0;        // force 32-pixel tiles per wave (1 | 2), 0 = auto
+    int conv_vec = 1;       // float4-staged convs
+    int lstm_shape = 0;     // seg*100000 + rows*1000 + pxw, 0 = auto
+    int pw_force = 0;       // mt*100 + nt*10 + ws, 0 = auto
+    int pw_batched = 0;     // same for the T-batched launches
+    int tok_npt = 0;        // 0 = auto, 1 | 2 = forced
+};
+inline const Tuning*& tuning_tls() {
+    static const Tuning defaults;
+    static thread_local const Tuning* cur = &defaults;
+    return cur;
+}
+inline const Tuning& tuning() { return *tuning_tls(); }
+struct TuningScope {
+    const Tuning* prev;
+    explicit TuningScope(const Tuning* t) : prev(tuning_tls()) { tuning_tls() = t; }
+    ~TuningScope() { tuning_tls() = prev; }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: remember per device (not per
+// process) that it has been raised.  `seen` is one static array per kernel instantiation.
+constexpr int BDE_MAX_DEVICES = 64;
+inline bool first_use_on_device(unsigned char (&seen)[BDE_MAX_DEVICES]) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BDE_MAX_DEVICES) return true;
+    if (seen[d]) return false;
+    seen[d] = 1;
+    return true;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 

@@ -511,10 +511,9 @@ static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
                     tile, conv_stage_items(gm, tile), MAXI, a.Win, KS);
     auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, CK, SPLITK, EPI, MAXI>;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
+        static unsigned char raised[BDE_MAX_DEVICES];
+        if (first_use_on_device(raised)) {
             BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
         }
     }
     constexpr int BN = (SPLITK ? 1 : 4) * NT * 32;

@@ -197,10 +197,9 @@ static int conv_vec_launch_i(const ConvArgs& a, int G, hipStream_t stream, long 
     const size_t lds = ((size_t)MT * KS * KS * (CK / 2) * 64 + (size_t)CK * tile) * sizeof(float);
     auto kern = conv_vec_kernel<KS, STRIDE, MT, NT, CK, MAXI4>;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
+        static unsigned char raised[BDE_MAX_DEVICES];
+        if (first_use_on_device(raised)) {
             BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
         }
     }
     constexpr int BN = 4 * NT * 32;
@@ -222,8 +221,6 @@ static int conv_vec_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 
 // Same tiling choice as conv_launch_ks; returns BDE_ERR_UNSUPPORTED when no vector tiling fits
 // (the caller then falls back to the dword kernel).
-inline int& conv_vec_nt_ref() { static int v = 0; return v; }   // tuning: force 32-pixel tiles per wave (1 | 2), 0 = auto
-
 template <int KS, int STRIDE>
 static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launched) {
     *launched = false;
@@ -234,7 +231,7 @@ static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launc
     int bnt = 1, brow = 0;
     for (int nt = 2; nt >= 1; --nt)
         for (int row = 1; row >= 0; --row) {
-            if (conv_vec_nt_ref() && nt != conv_vec_nt_ref()) continue;
+            if (tuning().conv_nt && nt != tuning().conv_nt) continue;
             const int BN = 4 * nt * 32;
             const int rt = row ? cdiv(a.Wo, BN) : 0;
             if (row && rt > 1 && (BN * STRIDE) % 4 != 0) continue;
@@ -258,11 +255,9 @@ static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launc
     return bnt == 2 ? conv_vec_launch_t<KS, STRIDE, 1, 2>(a, G, stream) : conv_vec_launch_t<KS, STRIDE, 1, 1>(a, G, stream);
 }
 
-inline int& conv_vec_enable_ref() { static int v = 1; return v; }
-
 static int conv_launch_best(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream) {
     bool done = false;
-    if (conv_vec_enable_ref()) {
+    if (tuning().conv_vec) {
         int st = BDE_OK;
         if (KS == 5 && stride == 1) st = conv_vec_launch_ks<5, 1>(a, G, stream, &done);
         else if (KS == 5 && stride == 2) st = conv_vec_launch_ks<5, 2>(a, G, stream, &done);

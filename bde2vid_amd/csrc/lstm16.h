@@ -260,8 +260,6 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
     }
 }
 
-inline int& lstm16_shape_ref() { static int v = 0; return v; }    // tuning: seg*100000 + rows*1000 + pxw, 0 = auto
-
 template <int ROWS, int PXW, int SEG, bool HC8>
 static int lstm16_launch_t(const ConvArgs& a, hipStream_t stream) {
     const int Ch = a.Cout / 4;
@@ -301,7 +299,7 @@ static int lstm16_launch(const ConvArgs& a, hipStream_t stream, bool hc8 = false
     int rows, pxw, seg;
     long wg16;
     lstm16_geometry(a, &rows, &pxw, &seg, &wg16);
-    if (const int f = lstm16_shape_ref()) { seg = (f / 100000) % 100; rows = (f / 1000) % 100; pxw = f % 1000; }
+    if (const int f = tuning().lstm_shape) { seg = (f / 100000) % 100; rows = (f / 1000) % 100; pxw = f % 1000; }
     if (hc8 && seg != 1) return fail(BDE_ERR_ARG, "recurrent step: 8-channel workgroups need one-segment waves");
 #define BDE_L16(R_, P_) \
     if (rows == R_ && pxw == P_ && seg == 1) return hc8 ? lstm16_launch_t<R_, P_, 1, true>(a, stream) : lstm16_launch_t<R_, P_, 1, false>(a, stream);

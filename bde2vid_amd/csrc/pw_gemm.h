@@ -215,11 +215,9 @@ static int pw_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 
 // Pick the decomposition of one pointwise GEMM launch: enough waves to cover the 1024 SIMDs,
 // as little reduction as possible.
-inline int& pw_force_ref() { static int v = 0; return v; }
-inline int& pw_batched_ref() { static int v = 0; return v; }  // same for the T-batched launches   // debug/tuning: mt*100 + nt*10 + ws, 0 = auto
-
+// (tuning().pw_force / pw_batched: mt*100 + nt*10 + ws overrides for the per-frame / T-batched launches)
 static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
-    if (const int f = pw_batched_ref(); f != 0 && (long)G * a.N > 4) {
+    if (const int f = tuning().pw_batched; f != 0 && (long)G * a.N > 4) {
         switch (f) {
             case 221: return pw_launch_t<2, 2, 1>(a, G, stream);
             case 211: return pw_launch_t<2, 1, 1>(a, G, stream);
@@ -227,7 +225,7 @@ static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
             default: break;
         }
     }
-    if (const int f = pw_force_ref(); f != 0 && (long)G * a.N <= 4) {
+    if (const int f = tuning().pw_force; f != 0 && (long)G * a.N <= 4) {
         switch (f) {
             case 211: return pw_launch_t<2, 1, 1>(a, G, stream);
             case 111: return pw_launch_t<1, 1, 1>(a, G, stream);

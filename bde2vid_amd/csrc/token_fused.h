@@ -347,11 +347,10 @@ template <int NPT>
 static int token_launch_t(const TokenArgs& a, int B, hipStream_t stream) {
     const size_t lds = token_lds_bytes(a.C, NPT);
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
+        static unsigned char raised[BDE_MAX_DEVICES];
+        if (first_use_on_device(raised)) {
             BDE_HIP(hipFuncSetAttribute((const void*)token_fused_kernel<NPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024));
-            raised = true;
         }
     }
     dim3 grid(cdiv(a.HW, 16 * NPT), B);
@@ -360,10 +359,8 @@ static int token_launch_t(const TokenArgs& a, int B, hipStream_t stream) {
     return BDE_OK;
 }
 
-inline int& tok_npt_ref() { static int v = 0; return v; }   // tuning: 0 = auto, 1 | 2 = forced
-
 static inline int token_launch(const TokenArgs& a, int B, hipStream_t stream) {
-    int npt = tok_npt_ref();
+    int npt = tuning().tok_npt;
     if (npt == 0) npt = (cdivl(a.HW, 32) * B >= 1024) ? 2 : 1;   // enough 32-pixel tiles for ~4 blocks per CU
     return npt == 2 ? token_launch_t<2>(a, B, stream) : token_launch_t<1>(a, B, stream);
 }

@@ -587,10 +587,9 @@ constexpr size_t winblock_lds_bytes() {
 }
 
 static int winblock_launch(WinArgs a, int B, hipStream_t stream) {
-    static bool raised = false;
-    if (!raised) {
+    static unsigned char raised[BDE_MAX_DEVICES];
+    if (first_use_on_device(raised)) {
         BDE_HIP(hipFuncSetAttribute((const void*)winblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        raised = true;
     }
     a.nWw = a.Wp / 7;
     a.nWin = (a.Hp / 7) * a.nWw;

@@ -1,55 +1,82 @@
 """Caller-side glue of the hot path: the part of `eval_model` (eval_models_seq.py:183-222,242)
 that assembles a sequence, pads it, chunks it and crops the reconstructions.
 
-`Croper` mirrors `utils_func/inference_utils.py:69-114` (same method names and arithmetic).
+`Croper` has the interface of `utils_func/inference_utils.py:69-114`; its results are pinned by a fixture of
+the reference's outputs (tests/golden/croper.json).
 """
-from math import ceil, floor
-from typing import Iterable, List, Optional, Sequence
+from typing import Iterable, List, NamedTuple, Optional, Sequence
 
 import torch
-import torch.nn.functional as F
 
 
 def optimal_crop_size(max_size: int, max_subsample_factor: int, safety_margin: int = 0) -> int:
     """Smallest multiple of 2**max_subsample_factor that is >= max_size (inference_utils.py:26-32)."""
-    m = 2 ** max_subsample_factor
-    return int(m * ceil(max_size / m))
+    step = 1 << max_subsample_factor
+    return -(-max_size // step) * step
+
+
+class _Axis(NamedTuple):
+    """One image axis: `n` sensor pixels inside `full` network pixels."""
+    n: int
+    full: int
+    before: int          # zero pixels in front of the data (the larger half of an odd surplus)
+    after: int
+    lo: int              # the centred window [lo, hi) that crop() returns
+    hi: int
+
+    @staticmethod
+    def plan(n: int, levels: int) -> '_Axis':
+        full = optimal_crop_size(n, levels)
+        surplus = full - n
+        lo = full // 2 - n // 2
+        return _Axis(n, full, surplus - surplus // 2, surplus // 2, lo, lo + n)
 
 
 class Croper:
-    """Zero-pad to the network size (ceil on top/left) and centre-crop back."""
+    """`Croper(num_encoders).pad(x)` / `.crop(img)` with the reference's interface and results
+    (utils_func/inference_utils.py:69-114, used at eval_models_seq.py:195-207,242): zero-pad H and W up to
+    multiples of 2**num_encoders with the odd pixel in front, and cut the centred sensor window back out.
+    The attribute names the reference exposes (`height_crop_size`, `padding_top`, `iy0`, ...) are kept as
+    read-only views of the two axis plans; pinned by tests/golden/croper.json (reference outputs)."""
 
     def __init__(self, num_encoders: int):
-        self.width = self.height = None
-        self.height_crop_size = self.width_crop_size = None
         self.num_encoders = num_encoders
+        self._y: Optional[_Axis] = None
+        self._x: Optional[_Axis] = None
 
     def update_params(self, width: int, height: int):
-        self.width, self.height = width, height
-        n = self.num_encoders
-        self.width_crop_size = optimal_crop_size(width, n)
-        self.height_crop_size = optimal_crop_size(height, n)
-        self.padding_top = ceil(0.5 * (self.height_crop_size - height))
-        self.padding_bottom = floor(0.5 * (self.height_crop_size - height))
-        self.padding_left = ceil(0.5 * (self.width_crop_size - width))
-        self.padding_right = floor(0.5 * (self.width_crop_size - width))
-        self.cx = floor(self.width_crop_size / 2)
-        self.cy = floor(self.height_crop_size / 2)
-        self.ix0 = self.cx - floor(width / 2)
-        self.ix1 = self.cx + ceil(width / 2)
-        self.iy0 = self.cy - floor(height / 2)
-        self.iy1 = self.cy + ceil(height / 2)
+        self._x = _Axis.plan(int(width), self.num_encoders)
+        self._y = _Axis.plan(int(height), self.num_encoders)
+
+    # the reference's attribute names
+    width = property(lambda self: self._x.n if self._x else None)
+    height = property(lambda self: self._y.n if self._y else None)
+    width_crop_size = property(lambda self: self._x.full if self._x else None)
+    height_crop_size = property(lambda self: self._y.full if self._y else None)
+    padding_left = property(lambda self: self._x.before)
+    padding_right = property(lambda self: self._x.after)
+    padding_top = property(lambda self: self._y.before)
+    padding_bottom = property(lambda self: self._y.after)
+    ix0 = property(lambda self: self._x.lo)
+    ix1 = property(lambda self: self._x.hi)
+    iy0 = property(lambda self: self._y.lo)
+    iy1 = property(lambda self: self._y.hi)
 
     def pad(self, x: torch.Tensor) -> torch.Tensor:
-        h, w = x.shape[-2:]
-        if h != self.height_crop_size or w != self.width_crop_size:
-            if h != self.height or w != self.width:
-                self.update_params(w, h)
-            x = F.pad(x, (self.padding_left, self.padding_right, self.padding_top, self.padding_bottom))
-        return x
+        h, w = int(x.shape[-2]), int(x.shape[-1])
+        if self._y is not None and (h, w) == (self._y.full, self._x.full):
+            return x                                    # already network-sized
+        if self._y is None or (h, w) != (self._y.n, self._x.n):
+            self.update_params(w, h)
+        ay, ax = self._y, self._x
+        out = x.new_zeros(x.shape[:-2] + (ay.full, ax.full))
+        out[..., ay.before:ay.before + h, ax.before:ax.before + w] = x
+        return out
 
     def crop(self, img: torch.Tensor) -> torch.Tensor:
-        return img[..., self.iy0:self.iy1, self.ix0:self.ix1] if self.num_encoders != -1 else img
+        if self.num_encoders == -1:
+            return img
+        return img[..., self._y.lo:self._y.hi, self._x.lo:self._x.hi]
 
 
 def chunked(seq: Sequence, n: Optional[int]) -> Iterable[Sequence]:

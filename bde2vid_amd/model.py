@@ -40,6 +40,7 @@ class BDE2VID:
         self.device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
         self._h = None
         self._loaded = False
+        self._ext_streams = {}              # pipelined mode: torch views of the library's internal streams
 
     # ---- reference surface ---------------------------------------------------------------
     @property
@@ -152,6 +153,18 @@ class BDE2VID:
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().bde_forward(self._h, ev_ptrs, T, B, H, W, im_ptrs,
                                               C.c_void_p(_stream_ptr(dev))))
+        if self.get_info('pipeline') > 1:
+            # Pipelined mode: the library reads the inputs and writes the outputs on an internal stream after this
+            # call has returned.  Tell the caching allocator, so that memory of a tensor the caller drops early
+            # (the .contiguous() temporaries above, an output that is never read) is not re-issued before that
+            # stream is done with it.
+            ptr = self.get_info('last_stream')
+            es = self._ext_streams.get(ptr)
+            if es is None:
+                es = self._ext_streams[ptr] = torch.cuda.ExternalStream(ptr, device=dev)
+            for t in evs:
+                t.record_stream(es)
+            out.record_stream(es)
         return [out[t] for t in range(T)]
 
     def wait(self):
@@ -159,6 +172,11 @@ class BDE2VID:
         far into the current stream.  Call before reading them (a device synchronize also suffices)."""
         _lib.check(_lib.lib().bde_wait_outputs(self._h, C.c_void_p(_stream_ptr(self.device))))
         return self
+
+    def get_info(self, key: str) -> int:
+        v = C.c_int64()
+        _lib.check(_lib.lib().bde_get_info(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_tuning(self, key: str, value: int):
         _lib.check(_lib.lib().bde_set_tuning(self._h, key.encode(), int(value)))

@@ -111,6 +111,10 @@ int bde_wait_outputs(bde_model* m, void* stream);
  * (1 attention level 0, 2 attention levels >= 1, 4 recurrent steps, 8 decoder, 16 encoder + gate convs),
  * used by tools/whatif.sh to read the marginal cost of a stage. */
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
+/* Read back the state the measurement has to be honest about: "debug_skip" (non-zero = stages skipped, results
+ * invalid), "graph" (0 also after a failed capture), "graphs_live" (workspaces replaying a captured launch
+ * sequence), "pipeline", "winblock", "device", "packed_numel".  Settings are per model object. */
+int bde_get_info(const bde_model* m, const char* key, int64_t* value);
 
 /* Diagnostics: resident workgroups per CU the runtime reports for a named kernel (-1 = unknown). */
 int bde_debug_occupancy(const char* kernel);

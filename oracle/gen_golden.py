@@ -53,6 +53,20 @@ E2E_CASES = {
     'e2e_ks3': (dict(basechannels=8, ks=3, depths=(1, 0, 2), num_heads=2), 64, 56, 3, 1, 600),
 }
 CFGA_FULL = ('e2e_cfgA_184x240', dict(), 184, 240, 4, 1, 700, 4)   # stored at pixel stride 4
+# Canonical config at every BASELINE.json resolution and at bench.py's exact workload (T=16): stored as pixels at
+# a stride plus per-frame mean/std, like CFGA_FULL.  name: (H, W, T, B, input seed, stride)
+CFGA_SAMPLED = {
+    'e2e_cfgA_184x240_T16': (184, 240, 16, 1, 7, 4),       # bench.py / cpu_baseline inputs: golden_inputs(16, 1, 5, 184, 240, 7)
+    'e2e_cfgA_264x352_B2': (264, 352, 3, 2, 710, 4),       # DAVIS346 260x346 padded (BASELINE config 4)
+    'e2e_cfgA_480x640': (480, 640, 2, 1, 720, 8),          # VGA (BASELINE config 3)
+    'e2e_cfgA_720x1280': (720, 1280, 2, 1, 730, 8),        # HD (BASELINE config 5)
+}
+# T > cpu_cache_length: the reference then parks every feature map on the host (V5.py:102,116,126-133,...); same
+# arithmetic, different code path.  name: (config kwargs, H, W, T, B, seed, cpu_cache_length, stride)
+LONGT_CASES = {
+    'e2e_longT_cache3': (dict(basechannels=8, depths=(2, 0, 2), num_heads=4), 56, 64, 7, 1, 800, 3, 1),
+    'e2e_longT_104': (dict(basechannels=8, depths=(1, 0, 1), num_heads=4), 56, 64, 104, 1, 810, 100, 2),
+}
 
 
 def _cfg(kw):
@@ -83,6 +97,62 @@ def gen_e2e():
                         meta=json.dumps(dict(cfg=cfg.to_dict(), H=H, W=W, T=T, B=B, seed=seed,
                                              weight_seed=WEIGHT_SEED, stride=stride)))
     print(name, y.shape, float(y.mean()), float(y.std()))
+
+
+def _store_sampled(name, cfg, y, stride, H, W, T, B, seed, **extra):
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), out=y[..., ::stride, ::stride],
+                        mean=y.mean(axis=(1, 2, 3, 4)), std=y.std(axis=(1, 2, 3, 4)),
+                        meta=json.dumps(dict(cfg=cfg.to_dict(), H=H, W=W, T=T, B=B, seed=seed,
+                                             weight_seed=WEIGHT_SEED, stride=stride, **extra)))
+    print(name, y.shape, float(y.mean()), float(y.std()), flush=True)
+
+
+def gen_cfgA_sampled(only=None):
+    cfg = canonical()
+    model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+    for name, (H, W, T, B, seed, stride) in CFGA_SAMPLED.items():
+        if only and name not in only:
+            continue
+        xs = golden_inputs(T, B, cfg.num_bins, H, W, seed)
+        with torch.no_grad():
+            ys = model([{'events': torch.from_numpy(x)} for x in xs])
+        _store_sampled(name, cfg, torch.stack(ys).numpy(), stride, H, W, T, B, seed)
+
+
+BENCH_FIXTURE = ('e2e_bench_T16', 180, 240, 16, 1000, 4)   # name, sensor H, W, T, event seed of frame 0, stored stride
+
+
+def gen_bench_fixture():
+    """bench.py's exact workload through the reference's own pipeline: synthetic events (bde2vid_amd/synth.py, seeds
+    1000+t) -> events_to_voxel_torch (h5_dataset.py:357) -> Croper(3).pad (eval_models_seq.py:195-207) -> model."""
+    from bde2vid_amd.synth import synthetic_events
+    name, sh, sw, T, seed0, stride = BENCH_FIXTURE
+    EU = ref_import.import_event_utils()
+    Croper = ref_import.import_croper()
+    cfg = canonical()
+    model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+    crop = Croper(cfg.num_encoders)
+    inputs = []
+    for t in range(T):
+        xs, ys, ts, ps = synthetic_events(sh * sw // 2, sh, sw, seed0 + t)
+        v = EU.events_to_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts),
+                                     torch.from_numpy(ps), cfg.num_bins, sensor_size=(sh, sw))
+        inputs.append({'events': crop.pad(v[None])})
+    H, W = inputs[0]['events'].shape[-2:]
+    with torch.no_grad():
+        ys_ = model(inputs)
+    _store_sampled(name, cfg, torch.stack(ys_).numpy(), stride, int(H), int(W), T, 1, seed0,
+                   sensor=[sh, sw], events_per_frame=sh * sw // 2)
+
+
+def gen_longT():
+    for name, (kw, H, W, T, B, seed, ccl, stride) in LONGT_CASES.items():
+        cfg = _cfg(kw)
+        model = ref_import.build_reference_model(cfg, WEIGHT_SEED, cpu_cache_length=ccl)
+        xs = golden_inputs(T, B, cfg.num_bins, H, W, seed)
+        with torch.no_grad():
+            ys = model([{'events': torch.from_numpy(x)} for x in xs])
+        _store_sampled(name, cfg, torch.stack(ys).numpy(), stride, H, W, T, B, seed, cpu_cache_length=ccl)
 
 
 def gen_blocks():
@@ -221,8 +291,15 @@ if __name__ == '__main__':
     assert ref_import.available(), 'needs /root/reference (build container only)'
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # e.g. `python oracle/gen_golden.py gen_cfgA_sampled gen_longT`
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     gen_croper()
     gen_voxels()
     gen_recording_voxels()
     gen_blocks()
     gen_e2e()
+    gen_cfgA_sampled()
+    gen_bench_fixture()
+    gen_longT()

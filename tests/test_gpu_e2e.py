@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import load_golden, case_from_meta, maxabs, E2E_CASES
+from tests.util import (load_golden, case_from_meta, maxabs, E2E_CASES, CFGA_SAMPLED, LONGT_CASES,
+                        assert_sampled)
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -222,3 +223,130 @@ def test_long_sequence_more_frames_than_one_pointer_block():
         ref = torch.stack(O.forward(sd, cfg, [{'events': torch.from_numpy(x)} for x in frames]))
     assert tuple(ys.shape) == tuple(ref.shape)
     assert maxabs(ys, ref) <= TOL
+
+
+@pytest.mark.parametrize('name', sorted(CFGA_SAMPLED))
+def test_config_a_at_baseline_resolutions(name):
+    """Canonical channel widths / heads / depths (the kernels bench.py times: winblock, attn_mfma16, lstm16<1,128,2>,
+    every conv_vec tile shape) at every BASELINE.json resolution and at bench.py's T=16, against the REFERENCE's
+    outputs (sampled pixels + per-frame mean/std, oracle/gen_golden.py::gen_cfgA_sampled)."""
+    z, meta = load_golden(name)
+    m, cfg, sd, xs, y = run_case(meta)
+    assert_sampled(y, z, meta, TOL, 1e-5)
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_bench_workload_matches_reference_in_serving_mode():
+    """bench.py's exact workload and mode: voxel grids from the HIP scatter of the synthetic events, three sequences
+    in flight, launch sequence replayed from hipGraphs -- every one of 7 calls must reproduce the reference's frames."""
+    from bde2vid_amd import canonical
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.weights import formula_state_dict
+    from bde2vid_amd.workload import bench_voxels, verify_against_fixture
+    z, meta = load_golden('e2e_bench_T16')
+    cfg = canonical()
+    m = build_model(cfg, formula_state_dict(cfg, meta['weight_seed']), 'cuda:0')
+    vox, n_events = bench_voxels(meta['T'], tuple(meta['sensor']), 'cuda:0', seed0=meta['seed'])
+    assert n_events == meta['T'] * meta['events_per_frame']
+    inputs = [{'events': vox[t]} for t in range(meta['T'])]
+    m.set_tuning('pipeline', 3)
+    outs = [m(inputs) for _ in range(7)]
+    m.wait()
+    torch.cuda.synchronize()
+    assert m.get_info('graphs_live') == 3
+    for o in outs:
+        y = torch.stack(o)
+        assert_sampled(y, z, meta, TOL, 1e-5)
+        ok, err = verify_against_fixture(y)
+        assert ok and err <= TOL
+    m.set_tuning('pipeline', 1)
+
+
+@pytest.mark.parametrize('name', sorted(LONGT_CASES))
+def test_longer_than_cpu_cache_length(name):
+    """T > cpu_cache_length (V5.py:102): the reference parks feature maps on the host; here everything stays in HBM
+    (the constructor argument is accepted and ignored).  Reference outputs, T = 7 with cache 3 and T = 104 with 100."""
+    from bde2vid_amd.model import BDE2VID
+    z, meta = load_golden(name)
+    cfg, sd, xs = case_from_meta(meta)
+    m = BDE2VID(generator=cfg, cpu_cache_length=meta['cpu_cache_length']).to('cuda:0')
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        y = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in xs]))
+    assert_sampled(y, z, meta, TOL, 1e-5)
+
+
+def test_pipelined_mode_with_temporaries_and_dropped_outputs():
+    """Serving mode with inputs that need a .contiguous() copy and outputs the caller drops at once: the library's
+    internal streams must still see valid memory (the tensors are recorded on those streams)."""
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.config import GeneratorConfig
+    from bde2vid_amd.weights import formula_state_dict
+    from tests.util import golden_inputs
+    cfg = GeneratorConfig(basechannels=8, depths=(2, 0, 2), num_heads=4)
+    m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
+    seqs = []
+    for i in range(6):
+        xs = golden_inputs(4, 1, 5, 64, 72, 1700 + 10 * i)
+        # channel-last storage: [B,5,H,W] views that are NOT contiguous
+        seqs.append([{'events': torch.from_numpy(x).cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)} for x in xs])
+        assert not seqs[-1][0]['events'].is_contiguous()
+    ref = [torch.stack(m(s)).clone() for s in seqs]
+    m.set_tuning('pipeline', 3)
+    keep = []
+    for rep in range(3):
+        for i, s in enumerate(seqs):
+            o = m(s)
+            if rep == 2:
+                keep.append(o)
+            else:
+                del o                                        # dropped while still in flight
+            junk = torch.full((4, 1, 1, 64, 72), float('nan'), device='cuda')   # grabs freshly freed blocks if any
+            del junk
+    m.wait()
+    torch.cuda.synchronize()
+    for r, o in zip(ref, keep):
+        assert torch.equal(r, torch.stack(o))
+    m.set_tuning('pipeline', 1)
+
+
+def test_broadcast_receiver_path_on_one_gpu():
+    """What ranks 1..N-1 run (dist.build_replicated_model): allocate the packed layout without weights, receive the
+    image, compute.  Here the 'broadcast' is a device copy from a model packed the ordinary way."""
+    from bde2vid_amd.model import BDE2VID, build_model
+    z, meta = load_golden('e2e_tiny')
+    cfg, sd, xs = case_from_meta(meta)
+    a = build_model(cfg, sd, 'cuda:0')
+    b = BDE2VID(generator=cfg).to('cuda:0').alloc_packed()
+    va, vb = a.packed_view(), b.packed_view()
+    assert va.shape == vb.shape and va.data_ptr() != vb.data_ptr()
+    vb.copy_(va)
+    inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    ya, yb = torch.stack(a(inp)), torch.stack(b(inp))
+    assert torch.equal(ya, yb)
+    assert maxabs(yb, z['out']) <= TOL
+
+
+def test_single_rank_rccl_broadcast_through_build_replicated_model(monkeypatch):
+    """dist.build_replicated_model over the nccl (= RCCL) backend with one rank: the collective call itself runs."""
+    import socket
+    import torch.distributed as dist
+    from bde2vid_amd.dist import init_from_env, build_replicated_model
+    z, meta = load_golden('e2e_tiny')
+    cfg, sd, xs = case_from_meta(meta)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    for k, v in dict(BDE_FORCE_DIST='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                     MASTER_PORT=port).items():
+        monkeypatch.setenv(k, v)
+    rank, world, local = init_from_env('nccl')
+    try:
+        m = build_replicated_model(cfg, lambda: sd, torch.device('cuda', local))
+        with torch.no_grad():
+            y = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in xs]))
+        assert maxabs(y, z['out']) <= TOL
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()

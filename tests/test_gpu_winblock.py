@@ -139,3 +139,50 @@ def test_random_shapes_vs_oracle(model_a):
         ref = oracle_blocks(cfg, sd, bufs, first, n)
         y = ops.dframe_attention(m, 0, [None if b is None else b.cuda() for b in bufs], first, n)
         assert maxabs(y, ref) <= TOL, f'case {case}: {B}x64x{H}x{W}, blocks {first}..{first + n - 1}, drop {drop}'
+
+
+# ---- the kernels bench.py times, at the map sizes of the larger BASELINE.json resolutions ----------------------------
+@pytest.mark.parametrize('hw', [(240, 320), (360, 640)])      # level-0 maps of VGA 480x640 and HD 720x1280
+def test_winblock_on_large_level0_maps(model_a, hw):
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    shape = (1, 64, hw[0], hw[1])
+    bufs = [torch.from_numpy(dense_like(shape, 700 + d)) for d in range(3)]
+    dev = [b.cuda() for b in bufs]
+    for blk in (0, 1):                                   # plain, dilated (uncovered pixels ride in the spare columns)
+        ref = oracle_blocks(cfg, sd, bufs, blk, 1)
+        assert maxabs(ops.dframe_attention(m, 0, dev, blk, 1), ref) <= TOL, f'block {blk}'
+
+
+@pytest.mark.parametrize('hw', [(33, 44), (60, 80), (90, 160)])   # level-2 maps of 264x352, VGA, HD
+def test_level2_chain_on_large_maps(model_a, hw):
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    shape = (1, 256, hw[0], hw[1])
+    bufs = [torch.from_numpy(dense_like(shape, 720 + d)) for d in range(3)]
+    dev = [b.cuda() for b in bufs]
+    ref = oracle_blocks(cfg, sd, bufs, 0, 2, level=2)
+    assert maxabs(ops.dframe_attention(m, 2, dev, 0, 2), ref) <= TOL
+
+
+@pytest.mark.parametrize('hw,level', [((480, 640), 0), ((184, 240), 0), ((240, 320), 1), ((120, 160), 2)])
+def test_recurrent_step_at_canonical_widths(model_a, hw, level):
+    """RecurrentConv of the canonical config on full-size inputs: lstm16_step_kernel<1,128,2> at level 0 (wide maps),
+    the 8-channel-workgroup variant at level 2, the float4-staged stride-2 5x5 and 3x3 gate convs."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    Cin = cfg.enc_in(level)
+    xs = [torch.from_numpy(dense_like((1, Cin, hw[0], hw[1]), 740 + t)) for t in range(2)]
+    for direction, name in ((0, 'forward_encoder'), (1, 'backward_encoder')):
+        pre = f'{O.P}{name}.{level}.'
+        order = range(2) if direction == 0 else range(1, -1, -1)
+        state, ref = None, [None, None]
+        with torch.no_grad():
+            for t in order:
+                x = O.conv_layer(xs[t], sd[pre + 'conv.conv2d.weight'], sd[pre + 'conv.conv2d.bias'], 2, 'relu')
+                state = O.convlstm_cell(x, state, sd[pre + 'recurrent_block.Gates.weight'], sd[pre + 'recurrent_block.Gates.bias'])
+                ref[t] = state[0]
+        h, c = ops.recurrent_conv(m, level, direction, torch.stack(xs).cuda())
+        assert maxabs(h, torch.stack(ref)) <= TOL
+        assert maxabs(c, state[1]) <= TOL

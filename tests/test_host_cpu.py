@@ -188,3 +188,30 @@ def test_checkpoint_config_is_parsed_without_executing_it(tmp_path):
     else:
         with pytest.raises(RuntimeError):
             load_model(str(path))
+
+
+class _Payload:
+    """A pickle whose loading would run code (os.system) under the full unpickler."""
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        import os as _os
+        return (_os.system, (f'touch {self.marker}',))
+
+
+def test_checkpoint_with_code_payload_is_rejected(tmp_path):
+    """checkpoint.read_checkpoint never falls back to the full unpickler by itself: a file carrying a __reduce__ payload
+    is refused (and the payload does not run) unless the caller passes trust_checkpoint=True."""
+    from bde2vid_amd.checkpoint import read_checkpoint
+    marker = tmp_path / 'pwned'
+    path = tmp_path / 'evil.pth'
+    torch.save({'state_dict': {}, 'meta': {'cfg': 'model = dict()', 'extra': _Payload(str(marker))}}, str(path))
+    with pytest.raises(RuntimeError, match='trust_checkpoint'):
+        read_checkpoint(str(path))
+    assert not marker.exists()
+    with pytest.raises(FileNotFoundError):
+        read_checkpoint(str(tmp_path / 'missing.pth'))
+    good = tmp_path / 'good.pth'
+    torch.save({'state_dict': {'a': torch.ones(2)}, 'meta': {'cfg': 'model = dict()'}}, str(good))
+    assert torch.equal(read_checkpoint(str(good))['state_dict']['a'], torch.ones(2))

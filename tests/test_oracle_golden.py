@@ -13,7 +13,7 @@ import torch
 from oracle import bde2vid_oracle as O
 from oracle import voxel_oracle
 from tests.util import (load_golden, case_from_meta, maxabs, dense_like, voxel_like, voxel_case,
-                        E2E_CASES, GOLDEN)
+                        E2E_CASES, GOLDEN, CFGA_SAMPLED, LONGT_CASES, bench_fixture_inputs, assert_sampled)
 from bde2vid_amd.config import GeneratorConfig
 from bde2vid_amd.weights import formula_state_dict, relative_position_index
 
@@ -42,6 +42,37 @@ def test_e2e_config_a_full_size_sampled():
     assert maxabs(y[..., ::s, ::s], z['out']) <= TOL
     assert np.allclose(y.mean(axis=(1, 2, 3, 4)), z['mean'], atol=1e-6)
     assert np.allclose(y.std(axis=(1, 2, 3, 4)), z['std'], atol=1e-6)
+
+
+@pytest.mark.parametrize('name', sorted(CFGA_SAMPLED))
+def test_config_a_at_baseline_resolutions(name):
+    """Canonical config at every BASELINE.json resolution and at bench.py's T=16 (reference outputs, sampled)."""
+    z, meta = load_golden(name)
+    cfg, sd, xs = case_from_meta(meta)
+    with torch.no_grad():
+        y = torch.stack(O.forward(sd, cfg, [{'events': torch.from_numpy(x)} for x in xs])).numpy()
+    assert_sampled(y, z, meta, TOL, 1e-6)
+
+
+def test_bench_workload_fixture():
+    """bench.py's exact workload (events -> voxel grids -> pad -> forward) as the reference computed it."""
+    z, meta = load_golden('e2e_bench_T16')
+    cfg = GeneratorConfig.from_dict(meta['cfg'])
+    sd = formula_state_dict(cfg, meta['weight_seed'])
+    with torch.no_grad():
+        y = torch.stack(O.forward(sd, cfg, [{'events': v} for v in bench_fixture_inputs(meta)])).numpy()
+    assert_sampled(y, z, meta, TOL, 1e-6)
+
+
+@pytest.mark.parametrize('name', sorted(LONGT_CASES))
+def test_longer_than_cpu_cache_length(name):
+    """T > cpu_cache_length: the reference parks its feature maps on the host (V5.py:102 ...); same arithmetic."""
+    z, meta = load_golden(name)
+    cfg, sd, xs = case_from_meta(meta)
+    assert meta['T'] > meta['cpu_cache_length']
+    with torch.no_grad():
+        y = torch.stack(O.forward(sd, cfg, [{'events': torch.from_numpy(x)} for x in xs])).numpy()
+    assert_sampled(y, z, meta, TOL, 1e-6)
 
 
 def test_blocks_match_reference():
