@@ -44,6 +44,7 @@ SIGNATURES = {
     'bde_debug_occupancy': (_I, [C.c_char_p]),
     'bde_debug_token_stamps': (_I, [_P, C.POINTER(_L), _I]),
     'bde_profile_reset': (_I, [_P, _I]),
+    'bde_profile_names': (_I, [_P, C.c_char_p, _L]),
     'bde_profile_get': (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_L)]),
     'bde_voxelize': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'bde_voxelize_batch': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),

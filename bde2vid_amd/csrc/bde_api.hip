@@ -484,6 +484,13 @@ struct ProfScope {
     }
 };
 
+// span names with an index ("lstm0", "dec_conv2"): interned, the spans keep the pointer
+static const char* pname(const char* base, int i) {
+    static std::map<std::string, std::string> names;
+    const std::string k = std::string(base) + std::to_string(i);
+    return names.emplace(k, k).first->second.c_str();
+}
+
 static const std::string GP = "generator.";
 
 static int get_raw(bde_model* m, const std::string& key, std::vector<int64_t> shape, const float** out) {
@@ -881,7 +888,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     e.act = ACT_RELU;
     e.in_gs = 0;
     e.out_gs = TB * C * hw;
-    { ProfScope ps(m, "enc_conv", s); BDE_TRY(run_conv(m, e, s)); }
+    { ProfScope ps(m, pname("enc_conv", l), s); BDE_TRY(run_conv(m, e, s)); }
     // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
     ConvCall gxc;
     gxc.pl = &m->gx[l];
@@ -892,7 +899,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     gxc.Ws = w;
     gxc.in_gs = TB * C * hw;
     gxc.out_gs = TB * 4 * C * hw;
-    { ProfScope ps(m, "gates_x", s); BDE_TRY(run_conv(m, gxc, s)); }
+    { ProfScope ps(m, pname("gates_x", l), s); BDE_TRY(run_conv(m, gxc, s)); }
     return BDE_OK;
 }
 
@@ -939,8 +946,7 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         a.Wo = w;
         a.nchunks = pl.nchunks;
         {
-            static const char* names[BDE_MAX_LEVELS] = {"lstm0", "lstm1", "lstm2", "lstm3", "lstm4", "lstm5", "lstm6", "lstm7"};
-            ProfScope ps(m, names[l], s);
+            ProfScope ps(m, pname("lstm", l), s);
             const bool hc8 = m->lstm_hc8 == 1 || (m->lstm_hc8 < 0 && lstm16_wants_hc8(a));
             if (hc8) {                                   // 8-channel workgroups: their own weight packing
                 a.wpk = m->P(m->lstm8[l].w_off);
@@ -980,7 +986,7 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
         // q | k | v of the current x
         const float* qkv = ws.qkv;
         if (i == blk0 && qkv_first) qkv = qkv_first;
-        else if (!have_qkv) BDE_TRY(run_pw(m, &ab.qkv, x, ws.qkv, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+        else if (!have_qkv) { ProfScope ps(m, pname("chain_qkv", l), s); BDE_TRY(run_pw(m, &ab.qkv, x, ws.qkv, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s)); }
         AttnArgs a;
         memset(&a, 0, sizeof a);
         a.q = qkv;
@@ -1003,8 +1009,11 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
         a.out_bs = C * HW;
         a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
         a.pt = pt; a.pl = plft; a.nWw = Wp / 7; a.dilated = dil ? 1 : 0;
-        if (C / c.num_heads == 16 && D * ATT_TOK <= 160 && tuning().attn_mfma) BDE_TRY(attn_mfma16_launch(a, B, s));
-        else BDE_TRY(attn_launch(a, B, s));
+        {
+            ProfScope ps(m, pname("chain_core", l), s);
+            if (C / c.num_heads == 16 && D * ATT_TOK <= 160 && tuning().attn_mfma) BDE_TRY(attn_mfma16_launch(a, B, s));
+            else BDE_TRY(attn_launch(a, B, s));
+        }
         float* dst = last ? out : (x == ws.xa ? ws.xb : ws.xa);
         if (fused) {
             TokenArgs ta;
@@ -1030,16 +1039,16 @@ static int run_attention_frame(bde_model* m, int l, const float* xq, const float
             ta.mask_pl = plft;
             ta.debug = m->tok_debug;
             ta.stamps = m->tok_stamps;
-            BDE_TRY(token_launch(ta, B, s));
+            { ProfScope ps(m, pname("chain_token", l), s); BDE_TRY(token_launch(ta, B, s)); }
             have_qkv = !last;
             x = dst;
             continue;
         }
         // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only)
-        BDE_TRY(run_pw(m, &ab.proj, ws.ao, ws.x1, B, HW, ACT_NONE, x, nullptr, dil ? W : 0, pt, plft, s));
+        { ProfScope ps(m, pname("chain_proj", l), s); BDE_TRY(run_pw(m, &ab.proj, ws.ao, ws.x1, B, HW, ACT_NONE, x, nullptr, dil ? W : 0, pt, plft, s)); }
         // x2 = x1 + fc2(GELU(fc1(LN(x1))))  (+ merged[t] after the last block)
-        BDE_TRY(run_pw(m, &ab.fc1, ws.x1, ws.hid, B, HW, ACT_GELU, nullptr, nullptr, 0, 0, 0, s));
-        BDE_TRY(run_pw(m, &ab.fc2, ws.hid, dst, B, HW, ACT_NONE, ws.x1, last ? addres : nullptr, 0, 0, 0, s));
+        { ProfScope ps(m, pname("chain_mlp_in", l), s); BDE_TRY(run_pw(m, &ab.fc1, ws.x1, ws.hid, B, HW, ACT_GELU, nullptr, nullptr, 0, 0, 0, s)); }
+        { ProfScope ps(m, pname("chain_mlp_out", l), s); BDE_TRY(run_pw(m, &ab.fc2, ws.hid, dst, B, HW, ACT_NONE, ws.x1, last ? addres : nullptr, 0, 0, 0, s)); }
         x = dst;
     }
     return BDE_OK;
@@ -1092,7 +1101,7 @@ static int run_attention_frame_win(bde_model* m, int l, const float* const* fram
         a.stamps = m->tok_stamps;
         a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw; a.pt = ph / 2; a.pl = pw / 2;
         a.dilated = (i % 2) == 1 ? 1 : 0;                    // DTransformer.py:362
-        BDE_TRY(winblock_launch(a, B, s));
+        { ProfScope ps(m, pname("winblock", l), s); BDE_TRY(winblock_launch(a, B, s)); }
         x = dst;
     }
     return BDE_OK;
@@ -1110,7 +1119,7 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
     if (winblock_ok(m, l)) {
         // one launch per block; the K|V of the neighbour frames are recomputed inside from the frames
         // themselves (refined in place for f < t, V5.py:166-169), so nothing else is staged per level
-        BDE_TRY(nchw_to_tok(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s));
+        { ProfScope ps(m, pname("to_tok", l), s); BDE_TRY(nchw_to_tok(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s)); }
         for (int t = 0; t < T; ++t) {
             const float* frames[BDE_MAX_FRAMES];
             for (int d = 0; d < D; ++d) {
@@ -1130,10 +1139,12 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         if (c.buffer_index[d] >= 0) need_un = true; else need_ref = true;
     }
     // K|V of every block for the still-unrefined frames, all T at once
-    if (need_un)
+    if (need_un) {
+        ProfScope ps(m, pname("chain_kv_all", l), s);
         BDE_TRY(run_pw(m, &al.kvall, ws.merged[l], ws.kvun[l], T * B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+    }
     // q|k|v of the first block for every frame at once: its input is the still-unrefined merged[t]
-    BDE_TRY(run_pw(m, &al.blocks[0].qkv, ws.merged[l], ws.qkv0[l], T * B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+    { ProfScope ps(m, pname("chain_qkv_all", l), s); BDE_TRY(run_pw(m, &al.blocks[0].qkv, ws.merged[l], ws.qkv0[l], T * B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s)); }
     for (int t = 0; t < T; ++t) {
         const float* kvslot[BDE_MAX_FRAMES];
         for (int d = 0; d < D; ++d) {
@@ -1144,8 +1155,10 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         }
         float* mt = ws.merged[l] + (long)t * fs;
         BDE_TRY(run_attention_frame(m, l, mt, kvslot, mt, mt, B, H, W, 0, al.depth, ws.qkv0[l] + (long)t * B * 3 * C * HW, s));
-        if (need_ref && t + 1 < T)
+        if (need_ref && t + 1 < T) {
+            ProfScope ps(m, pname("chain_kv", l), s);
             BDE_TRY(run_pw(m, &al.kvall, mt, ws.kvref[l] + (long)t * kvfs, B, HW, ACT_NONE, nullptr, nullptr, 0, 0, 0, s));
+        }
         if (on_frame) BDE_TRY(on_frame(m, t, ctx));
     }
     return BDE_OK;
@@ -1155,7 +1168,7 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
                        hipStream_t s) {
     const PackedLayer& pl = m->dec[j];
-    BDE_TRY(upsample2x_sum(in, skip, m->W().up, Hs, Ws, (long)N * pl.Cin, s));
+    { ProfScope ps(m, pname("dec_up", j), s); BDE_TRY(upsample2x_sum(in, skip, m->W().up, Hs, Ws, (long)N * pl.Cin, s)); }
     ConvCall d;
     d.pl = &pl;
     d.in = m->W().up;
@@ -1164,6 +1177,7 @@ static int run_decoder(bde_model* m, int j, const float* in, const float* skip, 
     d.Hs = 2 * Hs;
     d.Ws = 2 * Ws;
     d.act = ACT_RELU6;
+    ProfScope ps(m, pname("dec_conv", j), s);
     return run_conv(m, d, s);
 }
 
@@ -1287,6 +1301,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         }
         const long total = (long)nf * H_ * W_;
         long blocks = std::min<long>(cdivl(total, 256), 4096);
+        ProfScope ps(mm, "pred", st);
         hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x,
                            w.head + (long)f0 * mm->cfg.basechannels * H_ * W_, mm->P(mm->predw_off),
                            mm->P(mm->predb_off), w.out + (long)f0 * H_ * W_, mm->cfg.basechannels, (long)H_ * W_, total,
@@ -1314,7 +1329,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s, enc_done));
         enc_done = false;
         const long n = TB * C * h * w;
-        BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s));   // V5.py:137-147
+        { ProfScope ps(m, pname("merge", l), s); BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s)); }   // V5.py:137-147
         if (c.depths[l] > 0 && !(m->debug_skip & (l == 0 ? 1 : 2))) {
             static const char* names[BDE_MAX_LEVELS] = {"attn0", "attn1", "attn2", "attn3", "attn4", "attn5", "attn6", "attn7"};
             ProfScope ps(m, names[l], s);
@@ -1581,6 +1596,21 @@ int bde_profile_reset(bde_model* m, int32_t enable) {
     m->prof_on = enable != 0;
     for (auto& w : m->wslots)          // spans live inside the captured graph: re-capture
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
+    return BDE_OK;
+}
+
+int bde_profile_names(bde_model* m, char* buf, int64_t buflen) {
+    // distinct span names recorded since the last reset, separated by '\n' (truncated to buflen)
+    BDE_REQUIRE(m && buf && buflen > 0, "bad argument");
+    std::vector<std::string> seen;
+    std::string out;
+    for (auto& sp : m->prof)
+        if (std::find(seen.begin(), seen.end(), sp.name) == seen.end()) {
+            seen.push_back(sp.name);
+            out += sp.name;
+            out += '\n';
+        }
+    snprintf(buf, (size_t)buflen, "%s", out.c_str());
     return BDE_OK;
 }
 

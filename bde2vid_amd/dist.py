@@ -69,6 +69,14 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def min_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -5,21 +5,29 @@ A step = one `model.forward` over one synthetic sequence (BASELINE.json configs[
 single MI355X, 5x240x180 voxels padded to 5x184x240, seq_len 16, fp32, batch 1, config "A").
 Inputs are voxel grids produced by the HIP scatter from synthetic events and are resident in HBM
 before the timed region.  Multi-GPU: one process per GPU (torchrun), every rank runs its own
-sequences (weak scaling), one RCCL weight broadcast at start-up, no per-step collective.
+replica on its own sequences (weak scaling), one RCCL weight broadcast at start-up, no per-step
+collective.
+
+After the timed region the frames the LAST timed step produced (pipelined, replayed from the
+captured graphs) are compared with `tests/golden/e2e_bench_T16.npz` -- what the reference itself
+computed for these events -- on every rank; the JSON line carries `"verified": true` only then,
+and no line is printed when the library reports that stages were skipped (`debug_skip`).
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak (= fp32 vector peak)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
+ATOMIC_PEAK_GBPS = 1300.0       # MI355X_MICROARCH.md, global float atomics: ~1.3 TB/s of added bytes chip-wide
+PMC_FILE = os.path.join(REPO, 'profiles', 'r2_pmc.json')
 
 
 def log(msg):
@@ -55,71 +63,202 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def lstm_shape(ho, wo, ch, B):
-    """Tile shape csrc/lstm16.h picks for a [ch][ho][wo] hidden map (mirrors lstm16_launch; label only)."""
-    cdiv = lambda a, b: -(-a // b)
-    fill = lambda r, p: ho * cdiv(wo, 16) / (cdiv(ho, r) * cdiv(wo, p) * (r * p // 16))
-    rows, pxw, bf = 1, 64, -1.0
-    for r, p in ((1, 64), (2, 32), (4, 16)):
-        f = fill(r, p)
-        if f > bf + 0.02:
-            bf, rows, pxw = f, r, p
-    seg = 1
-    if cdiv(ho, rows) * cdiv(wo, pxw) * cdiv(ch, 16) * 2 * B > 1024 and fill(1, 128) >= bf - 0.08:
-        rows, pxw, seg = 1, 128, 2
-    return f'{rows},{pxw},{seg}'
+# ------------------------------------------------------------------------------------------------
+# algorithmic work of every timed launch (flops from the layer shapes; bytes = inputs + weights read
+# once, outputs written once)
+# ------------------------------------------------------------------------------------------------
+class Work:
+    """flops / bytes per launch of each profiled span of one forward (config, T, B, Hp, Wp)."""
+
+    def __init__(self, cfg, T, B, H, W):
+        self.cfg, self.T, self.B, self.H, self.W = cfg, T, B, H, W
+
+    def _lvl(self, l):
+        return self.cfg.enc_in(l), self.cfg.enc_out(l), (self.H >> (l + 1)) * (self.W >> (l + 1))
+
+    def attn_block_flops(self, l):
+        """One SwinTransformerBlock3D on one frame (DTransformer.py:286-306): q on the padded query-frame tokens, k|v on
+        the padded tokens of all D frames, scores and p*v over D*49 keys, proj, MLP (4C hidden) on the unpadded map."""
+        c = self.cfg
+        C, D = c.enc_out(l), c.frame_num
+        h, w = self.H >> (l + 1), self.W >> (l + 1)
+        npad = (-(-h // 7) * 7) * (-(-w // 7) * 7)
+        hw = h * w
+        return self.B * (2.0 * npad * C * C + 2.0 * npad * D * 2 * C * C + 4.0 * npad * D * 49 * C
+                         + 2.0 * npad * C * C + 2.0 * hw * 8 * C * C)
+
+    def flops(self, name):
+        """(flops per launch, bound) for a kernel span; None for spans without an entry."""
+        c, T, B = self.cfg, self.T, self.B
+        TB = T * B
+        m = re.fullmatch(r'([a-z_]+?)(\d*)', name)
+        if m is None:
+            return None
+        base, idx = m.group(1), int(m.group(2)) if m.group(2) else None
+        if base == 'head':
+            return 2.0 * c.basechannels * c.num_bins * c.ks ** 2 * self.H * self.W * TB, 'mfma'
+        if base == 'enc_conv':
+            cin, cout, hw = self._lvl(idx)
+            return 2 * TB * hw * 2.0 * cout * cin * c.ks ** 2, 'mfma'
+        if base == 'gates_x':
+            cin, cout, hw = self._lvl(idx)
+            return 2 * TB * hw * 2.0 * 4 * cout * cout * 9, 'mfma'
+        if base == 'lstm':
+            cin, cout, hw = self._lvl(idx)
+            return 2 * B * hw * (2.0 * 4 * cout * cout * 9 + 20.0 * cout), 'mfma'
+        if base in ('winblock', 'wideblock'):
+            return self.attn_block_flops(idx), 'mfma'
+        if base == 'dec_conv':
+            l = c.num_encoders - 1 - idx
+            cin, cout = c.enc_out(l), c.enc_in(l)
+            return TB * (self.H >> l) * (self.W >> l) * 2.0 * cout * cin * c.ks ** 2, 'mfma'
+        C = c.enc_out(idx) if idx is not None and idx < c.num_encoders else 0
+        hw = (self.H >> (idx + 1)) * (self.W >> (idx + 1)) if idx is not None and idx < c.num_encoders else 0
+        if base == 'chain_qkv':
+            return B * hw * 2.0 * 3 * C * C, 'mfma'
+        if base == 'chain_qkv_all':
+            return TB * hw * 2.0 * 3 * C * C, 'mfma'
+        if base == 'chain_kv':
+            return B * hw * 2.0 * c.depths[idx] * 2 * C * C, 'mfma'
+        if base == 'chain_kv_all':
+            return TB * hw * 2.0 * c.depths[idx] * 2 * C * C, 'mfma'
+        if base == 'chain_core':
+            h, w = self.H >> (idx + 1), self.W >> (idx + 1)
+            npad = (-(-h // 7) * 7) * (-(-w // 7) * 7)
+            return B * 4.0 * npad * c.frame_num * 49 * C, 'mfma'
+        if base == 'chain_proj':
+            return B * hw * 2.0 * C * C, 'mfma'
+        if base in ('chain_mlp_in', 'chain_mlp_out'):
+            return B * hw * 2.0 * 4 * C * C, 'mfma'
+        if base == 'chain_token':
+            return B * hw * 2.0 * (C * C + 8 * C * C + 3 * C * C), 'mfma'
+        return None
+
+    def first_step_flops(self, l):
+        """The first step of a sweep starts from h = 0 and skips the contraction: pointwise flops only."""
+        cin, cout, hw = self._lvl(l)
+        return 2 * self.B * hw * 20.0 * cout
+
+    def stage_flops(self):
+        """Per FORWARD: encoder (north star: encoder convs + gate convs + recurrent steps), attention levels, decoder, head."""
+        c, T, B = self.cfg, self.T, self.B
+        enc = 0.0
+        for l in range(c.num_encoders):
+            cin, cout, hw = self._lvl(l)
+            enc += 2 * B * T * hw * (2.0 * cout * cin * c.ks ** 2 + 2.0 * 4 * cout * 2 * cout * 9 + 20.0 * cout)
+            enc -= 2 * B * hw * 2.0 * 4 * cout * cout * 9           # h = 0 at the first step of each sweep
+        out = {'encoder_stage': enc, 'head': self.flops('head')[0]}
+        for l in range(c.num_encoders):
+            if c.depths[l] > 0:
+                out[f'attention_l{l}'] = T * c.depths[l] * self.attn_block_flops(l)
+        out['decoder'] = sum(self.flops(f'dec_conv{j}')[0] for j in range(c.num_encoders))
+        return out
 
 
-def lstm_flops_per_launch(cfg, B, H, W, level):
-    """Algorithmic flops of ONE recurrent ConvLSTM step launch (both directions):
-    h-part of the gates conv, 2 * (4C) * C * 9 per pixel, plus ~20 flop/px/channel pointwise."""
-    C = cfg.enc_out(level)
-    hw = (H >> (level + 1)) * (W >> (level + 1))
-    return 2 * B * hw * (2.0 * 4 * C * C * 9 + 20.0 * C)
+KERNEL_OF_SPAN = [
+    # span name pattern -> (regex on the rocprofv3 kernel name, readable description)
+    (r'lstm(\d)', r'lstm16_step_kernel', 'recurrent ConvLSTM step of level {0}, both directions (csrc/lstm16.h)'),
+    (r'winblock(\d)', r'winblock_kernel', 'one temporal window-attention block of level {0} per launch (csrc/winblock.h)'),
+    (r'wideblock(\d)', r'wideblock_', 'temporal window-attention block of level {0} (csrc/wideblock.h)'),
+    (r'gates_x(\d)', r'conv_vec_kernel<3, 1', 'x-part of the ConvLSTM gates of level {0}, 3x3 conv batched over T, both directions (csrc/conv_vec.h)'),
+    (r'enc_conv(\d)', r'conv_vec_kernel<5, 2', 'encoder 5x5 stride-2 conv of level {0}, batched over T, both directions (csrc/conv_vec.h)'),
+    (r'dec_conv(\d)', r'conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_vec.h)'),
+    (r'head', r'conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_vec.h)'),
+    (r'chain_(\w+?)(\d)', r'pw_gemm_kernel|attn_mfma16_kernel|attn_core_kernel|token_fused_kernel', 'split attention path of level {1}: {0}'),
+]
 
 
-def synth_voxels(T, H, W, sensor_hw, device, seed0=1000):
-    from bde2vid_amd.events import events_to_voxel_batch
-    from bde2vid_amd.synth import synthetic_events
-    sh, sw = sensor_hw
-    packs = [synthetic_events(sh * sw // 2, sh, sw, seed0 + t) for t in range(T)]
-    off = np.cumsum([0] + [len(p[0]) for p in packs])
-    cat = [torch.from_numpy(np.concatenate([p[k] for p in packs])) for k in range(4)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    grids = events_to_voxel_batch(*cat, off, 5, sensor_size=(sh, sw), device=device)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    pt, pl = -(-(H - sh) // 2), -(-(W - sw) // 2)
-    out = torch.zeros((T, 1, 5, H, W), device=device)
-    out[:, 0, :, pt:pt + sh, pl:pl + sw] = grids
-    return out, int(off[-1]), dt
+def describe_span(name):
+    for pat, kre, desc in KERNEL_OF_SPAN:
+        m = re.fullmatch(pat, name)
+        if m:
+            return kre, desc.format(*m.groups())
+    return None, name
 
 
-def voxel_native_rate(T, sensor_hw, device, reps=20):
-    """Events/s of the native-column scatter (bde_voxelize_events) with the columns resident in HBM."""
+def pmc_traffic(span, avg_us):
+    """HBM bytes per launch of the kernel behind `span` from the committed rocprofv3 --pmc passes of THIS round
+    (tools/gpu_pmc_all.sh -> profiles/r2_pmc.json), with provenance; None when the file has no such kernel."""
+    try:
+        with open(PMC_FILE) as f:
+            pmc = json.load(f)
+    except Exception:
+        return None, None
+    ent = pmc.get('spans', {}).get(span)
+    if not ent:
+        return None, None
+    prov = {'file': os.path.relpath(PMC_FILE, REPO), 'kernel': ent.get('kernel'), 'dispatches': ent.get('dispatches'),
+            'fetch_bytes_raw': ent.get('fetch_bytes'), 'write_bytes': ent.get('write_bytes'),
+            'avg_us_in_pmc_pass': ent.get('avg_us'), 'tag': pmc.get('tag'), 'note': pmc.get('note')}
+    return ent.get('hbm_bytes_per_launch'), prov
+
+
+def voxel_report(device, T, sensor_hw, n_events, vox_dt):
+    """Event binning: the bench's own grids (incl. H2D), the native-column scatter with columns resident in HBM, one
+    large launch against the float-atomic roof, and the reference's algorithm timed on one host core."""
+    import numpy as np
+    import torch
     from bde2vid_amd.events import events_to_voxel_windows
     from bde2vid_amd.synth import synthetic_recording
     sh, sw = sensor_hw
-    n = T * (sh * sw // 2)
-    xs, ys, ts, ps, _ = synthetic_recording(n, sh, sw, 4, 77)
-    idx = np.arange(T + 1, dtype=np.int64) * (n // T)
-    cols = [torch.from_numpy(a).to(device) for a in (xs, ys, ts, ps)]
-    events_to_voxel_windows(*cols, idx, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
-    torch.cuda.synchronize()
+    out = {'events_per_s': n_events / vox_dt, 'events': n_events,
+           'note': 'HIP scatter incl. H2D of the events; outside the timed region'}
+
+    def run(n, nwin, reps):
+        xs, ys, ts, ps, _ = synthetic_recording(n, sh, sw, 4, 77)
+        idx = np.arange(nwin + 1, dtype=np.int64) * (n // nwin)
+        cols = [torch.from_numpy(a).to(device) for a in (xs, ys, ts, ps)]
+        idx_d = torch.from_numpy(idx)
+        events_to_voxel_windows(*cols, idx_d, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            events_to_voxel_windows(*cols, idx_d, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) * 1e-3 / reps
+        nn = int(idx[-1])
+        read_b, atomic_b, fill_b = nn * 13, nn * 2 * 4, nwin * 5 * sh * sw * 4
+        return dict(events=nn, windows=nwin, events_per_s=nn / dt, ms_per_call=dt * 1e3,
+                    GBps=(read_b + atomic_b + fill_b) / dt / 1e9, atomic_GBps=atomic_b / dt / 1e9)
+    small = run(T * (sh * sw // 2), T, 20)
+    small['note'] = ('int16/int16/float64/bool columns resident in HBM, one grid per window, zero-fill included; '
+                     '13 B read + 2 float atomics per event; HIP events on the launch stream; launch-bound at this size')
+    out['native_columns'] = small
+    big = run(24_000_000, 64, 3)
+    big['roofline'] = {'bound': 'hbm (float atomics)', 'achieved': big['atomic_GBps'], 'peak': ATOMIC_PEAK_GBPS, 'unit': 'GB/s',
+                       'frac': big['atomic_GBps'] / ATOMIC_PEAK_GBPS,
+                       'note': 'added bytes (2 x 4 B per event) / time against the ~1.3 TB/s chip-wide float-atomic rate; '
+                               'whole-kernel bytes (columns + atomics + zero-fill) in GBps'}
+    out['native_columns_24M'] = big
+    return out
+
+
+def voxel_cpu_baseline(sensor_hw):
+    """The reference's binning algorithm (B passes of index_put_(accumulate=True), event_utils.py:466-509) restated in
+    oracle/voxel_oracle.py, on one host core: reported baseline, never the product."""
+    import torch
+    from oracle import voxel_oracle
+    sh, sw = sensor_hw
+    n = 2_000_000
+    xs, ys, ts, ps = voxel_oracle.synthetic_events(n, sh, sw, 5)
+    t = [torch.from_numpy(a) for a in (xs, ys, ts, ps)]
+    torch.set_num_threads(1)
+    voxel_oracle.events_to_voxel_indexput(*[a[:1000] for a in t], 5, (sh, sw))
     t0 = time.perf_counter()
-    for _ in range(reps):
-        events_to_voxel_windows(*cols, idx, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
-    torch.cuda.synchronize()
+    reps = 0
+    while time.perf_counter() - t0 < 3.0:
+        voxel_oracle.events_to_voxel_indexput(*t, 5, (sh, sw))
+        reps += 1
     dt = (time.perf_counter() - t0) / reps
-    bytes_per_call = n * 13 + n * 2 * 4 + T * 5 * sh * sw * 4      # columns + two float atomics per event + zero-fill
-    return dict(events_per_s=n / dt, events=n, windows=T, GBps=bytes_per_call / dt / 1e9,
-                note='int16/int16/float64/bool columns resident in HBM, one grid per window, zero-fill included; '
-                     '13 B read + 2 float atomics per event')
+    return dict(value=n / dt, unit='events/s', cores=1, kind='port',
+                sample=f'{reps} x {n} events into 5x{sh}x{sw}, torch {torch.__version__} CPU index_put_(accumulate), {dt*1e3:.0f} ms each')
 
 
 def cpu_baseline(cfg, sd, H, W, T):
     """CPU restatement (oracle) timed on the host cores: reported baseline, never the product."""
+    import torch
     from oracle import bde2vid_oracle as O
     from oracle.gen_golden import golden_inputs
     cores = host_cores()
@@ -131,6 +270,20 @@ def cpu_baseline(cfg, sd, H, W, T):
         dt = time.perf_counter() - t0
     return dict(value=T / dt, unit='frames/s', cores=cores, kind='port',
                 sample=f'one oracle forward, T={T}, 5x{H}x{W}, torch {torch.__version__} CPU, {dt:.1f} s')
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (this process has not touched
+    the GPU yet) and relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    log(f'--gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks as child processes')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -145,20 +298,26 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipeline', type=int, default=3, help='independent sequences in flight per GPU (1..4)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     # stdout carries exactly one JSON line: everything else a library prints there (RCCL's version banner at
     # communicator creation, for one) is sent to stderr
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
 
+    import ctypes as C
+    import torch
     from bde2vid_amd import canonical, _lib
-    from bde2vid_amd.dist import init_from_env, build_replicated_model, max_over_ranks, barrier
+    from bde2vid_amd.dist import init_from_env, build_replicated_model, max_over_ranks, min_over_ranks, barrier
     from bde2vid_amd.weights import formula_state_dict
     from bde2vid_amd.harness import Croper
+    from bde2vid_amd import workload
 
     log('start')
     rank, world, local = init_from_env()
-    assert world == max(args.gpus, 1) or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
+    if world != max(args.gpus, 1):
+        raise SystemExit(f'launched with WORLD_SIZE={world} but --gpus {args.gpus}')
     device = torch.device('cuda', local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     cfg = canonical()
@@ -168,21 +327,30 @@ def main():
         sd_holder['sd'] = formula_state_dict(cfg)
         return sd_holder['sd']
     model = build_replicated_model(cfg, get_sd, device)
-    for kv in os.environ.get('BDE_TUNING', '').split(','):
+    tuning = os.environ.get('BDE_TUNING', '')
+    for kv in tuning.split(','):
         if '=' in kv:
             k, v = kv.split('=')
             model.set_tuning(k, int(v))
+    if model.get_info('debug_skip') != 0:
+        raise SystemExit('debug_skip is set: stages of the forward are skipped, this is not a measurement')
     log('weights packed and resident')
 
     croper = Croper(cfg.num_encoders)
     croper.update_params(args.width, args.height)
     H, W, T, B = croper.height_crop_size, croper.width_crop_size, args.seq_len, args.batch
-    vox, n_events, vox_dt = synth_voxels(T, H, W, (args.height, args.width), device, seed0=1000 + 97 * rank)
+    # every rank reconstructs the same synthetic recording (its own replica, its own copy): the reference's frames
+    # for it are committed, so every rank -- the broadcast receivers included -- can check what it computed
+    vox, n_events, vox_dt = workload.bench_voxels(T, (args.height, args.width), device, seed0=1000)
     if B > 1:
         vox = vox.repeat(1, B, 1, 1, 1)
     inputs = [{'events': vox[t]} for t in range(T)]
     log(f'voxel grids ready ({n_events} events in {vox_dt*1e3:.1f} ms)')
+    fmeta = workload.fixture_meta()
+    can_verify = bool(fmeta and (T, B, H, W) == (fmeta['T'], fmeta['B'], fmeta['H'], fmeta['W'])
+                      and [args.height, args.width] == fmeta['sensor'])
 
+    L = _lib.lib()
     with torch.no_grad():
         # one-time setup (untimed, part of model initialisation): each pipeline slot needs one eager call
         # (workspace allocation, kernel attributes) and one more to capture its hipGraph
@@ -191,102 +359,129 @@ def main():
             model(inputs)
         model.wait()
         torch.cuda.synchronize(device)
-        log('workspaces allocated, launch graphs captured')
+        graphs_live = model.get_info('graphs_live')
+        log(f'workspaces allocated, {graphs_live} launch graph(s) captured')
         for i in range(args.warmup):
             model(inputs)
         model.wait()
         torch.cuda.synchronize(device)
         log(f'{args.warmup} warmup steps done')
-        L = _lib.lib()
         barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
+        last = None
         for _ in range(args.steps):
-            model(inputs)
+            last = model(inputs)
         model.wait()
         torch.cuda.synchronize(device)
         barrier()
         elapsed = time.perf_counter() - t0
-        # Kernel roofline: HIP-event spans around every launch of the recurrent step kernel.  Events
-        # recorded inside a replayed hipGraph cannot be read back, so the spans come from a few extra
-        # EAGER, un-pipelined steps run right after the timed region (same inputs, same kernels).
+        if model.get_info('debug_skip') != 0:
+            raise SystemExit('debug_skip was set during the timed region')
+        # ---- the frames of the last timed step against the reference's ------------------------------
+        verified, verr = None, None
+        if can_verify:
+            ok, verr = workload.verify_against_fixture(torch.stack(last))
+            verified = bool(min_over_ranks(1.0 if ok else 0.0, device) > 0.5)
+            verr = max_over_ranks(verr, device)
+            log(f'last timed step vs reference frames: max abs err {verr:.2e} -> verified={verified}')
+        # ---- per-kernel spans: HIP events around every launch, on the launch stream.  Events recorded inside a
+        # replayed hipGraph cannot be read back, so the spans come from a few extra EAGER, un-pipelined steps
+        # run right after the timed region (same inputs, same kernels).
+        n_eager = min(args.steps, 3)
         model.set_tuning('pipeline', 1)
         model.set_tuning('graph', 0)
         L.bde_profile_reset(model._h, 1)
-        for _ in range(min(args.steps, 3)):
+        for _ in range(n_eager):
             model(inputs)
         torch.cuda.synchronize(device)
     elapsed = max_over_ranks(elapsed, device)
     log(f'timed region done: {elapsed:.3f} s for {args.steps} steps')
 
     if rank == 0:
-        import ctypes as C
-        frames = args.steps * T * B * world
-        ms = C.c_double()
-        cnt = C.c_int64()
-        level = 0
-        L.bde_profile_get(model._h, b'lstm0', C.byref(ms), C.byref(cnt))
-        fl = lstm_flops_per_launch(cfg, B, H, W, level)
-        avg_s = (ms.value / max(cnt.value, 1)) * 1e-3
-        # the first step of a sweep starts from h = 0 and skips the contraction (one launch in T): its span is
-        # in the total, its contraction flops are not
-        n_eager = min(args.steps, 3)
-        pointwise = 2 * B * (H >> 1) * (W >> 1) * 20.0 * cfg.enc_out(0)
-        flops_total = (cnt.value - n_eager) * fl + n_eager * pointwise
-        achieved = flops_total / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        # encoder stage of the north star (encoder convs + gate convs + recurrent steps, SURVEY.md §8d: 45.9 GFLOP per
-        # 184x240 frame): HIP-event spans of the same eager steps
-        enc_ms = 0.0
-        for nm in [b'enc_conv', b'gates_x'] + [b'lstm%d' % l for l in range(cfg.num_encoders)]:
+        buf = C.create_string_buffer(8192)
+        L.bde_profile_names(model._h, buf, len(buf))
+        names = [n for n in buf.value.decode().split('\n') if n]
+        spans = {}
+        for nm in names:
             t_, c_ = C.c_double(), C.c_int64()
-            L.bde_profile_get(model._h, nm, C.byref(t_), C.byref(c_))
-            enc_ms += t_.value
-        enc_flops = 0.0
+            L.bde_profile_get(model._h, nm.encode(), C.byref(t_), C.byref(c_))
+            spans[nm] = (t_.value, int(c_.value))
+        work = Work(cfg, T, B, H, W)
+        kernels = {}
+        for nm, (ms, cnt) in spans.items():
+            fb = work.flops(nm)
+            if fb is None or cnt == 0 or ms <= 0:
+                continue
+            fl, bound = fb
+            total_fl = cnt * fl
+            if nm.startswith('lstm'):                       # first step of each sweep: no contraction
+                l = int(nm[4:])
+                total_fl = (cnt - n_eager) * fl + n_eager * work.first_step_flops(l)
+            kernels[nm] = dict(ms_per_forward=ms / n_eager, launches_per_forward=cnt / n_eager, avg_us=ms / cnt * 1e3,
+                               flops_per_launch=fl, achieved=total_fl / (ms * 1e-3) / 1e12, bound=bound)
+        fwd_ms = spans.get('forward', (0.0, 0))[0] / max(n_eager, 1)
+        for nm, k in kernels.items():
+            k['share'] = k['ms_per_forward'] / fwd_ms if fwd_ms > 0 else None
+            k['frac'] = k['achieved'] / FP32_MFMA_PEAK_TFLOPS
+        dom = max(kernels, key=lambda n: kernels[n]['ms_per_forward'])
+        dk = kernels[dom]
+        kre, desc = describe_span(dom)
+        traffic, prov = pmc_traffic(dom, dk['avg_us'])
+        # stages (same eager steps): encoder = enc convs + gate convs + recurrent steps (the north star's yardstick)
+        sf = work.stage_flops()
+        stage_ms = {'encoder_stage': sum(ms for nm, (ms, _) in spans.items() if re.fullmatch(r'(enc_conv|gates_x|lstm)\d', nm)),
+                    'head': spans.get('head', (0, 0))[0],
+                    'decoder': sum(ms for nm, (ms, _) in spans.items() if re.fullmatch(r'dec_(conv|up)\d', nm)) + spans.get('pred', (0, 0))[0]}
         for l in range(cfg.num_encoders):
-            cin, cout = cfg.enc_in(l), cfg.enc_out(l)
-            hw = (H >> (l + 1)) * (W >> (l + 1))
-            # both directions: stride-2 k x k conv, 3x3 gate conv on [x | h], ~20 flop per (pixel, channel) pointwise
-            enc_flops += 2 * B * T * hw * (2.0 * cout * cin * cfg.ks ** 2 + 2.0 * 4 * cout * 2 * cout * 9 + 20.0 * cout)
-        enc_flops -= sum(2 * B * (H >> (l + 1)) * (W >> (l + 1)) * 2.0 * 4 * cfg.enc_out(l) ** 2 * 9 for l in range(cfg.num_encoders))  # h = 0 at the first step
-        enc_flops *= n_eager
-        enc_tf = enc_flops / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (raw counters)
-            with open(os.path.join(REPO, 'profiles', 'r1b_lstm0_pmc.json')) as f:
-                traffic = json.load(f)['hbm_bytes_per_launch_raw']
-        except Exception:
-            pass
+            if cfg.depths[l] > 0:
+                stage_ms[f'attention_l{l}'] = spans.get(f'attn{l}', (0, 0))[0]
+        stages = {}
+        for nm, fl in sf.items():
+            ms = stage_ms.get(nm, 0.0)
+            if ms > 0:
+                tf = fl * n_eager / (ms * 1e-3) / 1e12
+                stages[nm] = dict(flops_per_forward=fl, ms_per_forward=ms / n_eager, achieved=tf, unit='TFLOP/s',
+                                  frac=tf / FP32_MFMA_PEAK_TFLOPS)
+        frames = args.steps * T * B * world
         out = {
             'metric': 'reconstructed frames/sec at 5x240x180 voxels, seq_len=16',
             'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'verified': verified,
+            'verification': ({'against': 'tests/golden/e2e_bench_T16.npz (the reference\'s frames for these events)',
+                              'what': 'frames of the last timed step (pipelined, graph replay), every rank', 'max_abs_err': verr,
+                              'tolerance': workload.TOLERANCE} if can_verify else
+                             {'against': None, 'why': 'a reference fixture exists only for the default workload (16 x 5x180x240, B=1)'}),
             'config': {'workload': f'BDE2VID.forward config A (5 bins, 32 ch, depths [4,0,6], 16 heads, D=3), '
                                    f'{T} frames of 5x{args.height}x{args.width} (padded {H}x{W}), batch {B}, '
                                    f'random-init formula weights, one independent sequence per step per GPU',
                        'seq_len': T, 'height': args.height, 'width': args.width, 'batch': B,
-                       'parallelism': f'{world} replicas, sequences sharded, 1 RCCL weight broadcast; per GPU '
-                                      f'{args.pipeline} independent sequence(s) in flight (double-buffered workspaces), '
-                                      f'launch sequence replayed from a hipGraph'},
-            'roofline': {'kernel': f'lstm16_step_kernel<{lstm_shape(H // 2, W // 2, cfg.basechannels * 2, B)}> (level-0 recurrent ConvLSTM step, both directions)',
-                         'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'launches': int(cnt.value), 'avg_us': avg_s * 1e6, 'flops_per_launch': fl,
-                         'flops_counted': flops_total,
-                         'encoder_stage': {'what': 'encoder convs + gate convs + recurrent steps of all levels (the fused '
-                                                   'conv+ConvLSTM encoder of the north star), same eager steps',
-                                           'flops': enc_flops, 'ms': enc_ms, 'achieved': enc_tf, 'unit': 'TFLOP/s',
-                                           'frac': enc_tf / FP32_MFMA_PEAK_TFLOPS},
-                         'measured': 'HIP events on the launch stream around each launch, over 3 eager un-pipelined '
+                       'tuning': tuning or None, 'pipeline': args.pipeline,
+                       'graph_replay': bool(graphs_live == args.pipeline),
+                       'graphs_captured': graphs_live,
+                       'parallelism': f'{world} replica(s), sequences sharded, 1 RCCL weight broadcast; per GPU '
+                                      f'{args.pipeline} independent sequence(s) in flight'},
+            'roofline': {'kernel': f'{dom}: {desc}', 'rocprof_kernel': kre, 'bound': dk['bound'],
+                         'achieved': dk['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': dk['frac'],
+                         'traffic': traffic, 'traffic_source': prov,
+                         'launches_per_forward': dk['launches_per_forward'], 'avg_us': dk['avg_us'],
+                         'flops_per_launch': dk['flops_per_launch'], 'share_of_forward': dk['share'],
+                         'chosen': 'the kernel with the largest total time among the HIP-event spans of this run',
+                         'stages': stages,
+                         'kernels': {nm: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()}
+                                     for nm, kk in sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_forward'])},
+                         'eager_forward_ms': fwd_ms,
+                         'measured': f'HIP events on the launch stream around each launch, over {n_eager} eager un-pipelined '
                                      'steps run right after the timed region (events inside hipGraph replays cannot be read); '
-                                     'achieved = flops of all those launches (the first step of a sweep has no contraction) / their total time'},
-            'voxelize': {'events_per_s': n_events / vox_dt, 'events': n_events,
-                         'note': 'HIP scatter incl. H2D of the events; outside the timed region',
-                         'native_columns': voxel_native_rate(T, (args.height, args.width), device)},
+                                     'achieved = algorithmic flops of those launches / their total time'},
+            'voxelize': voxel_report(device, T, (args.height, args.width), n_events, vox_dt),
         }
         if world == 1 and not args.no_cpu_baseline:
             log(f'cpu baseline on {host_cores()} host cores ...')
             out['cpu_baseline'] = cpu_baseline(cfg, sd_holder['sd'], H, W, T)
+            out['voxelize']['cpu_baseline'] = voxel_cpu_baseline((args.height, args.width))
         print(json.dumps(out), file=json_out, flush=True)
     barrier()
     import torch.distributed as dist

@@ -122,10 +122,13 @@ int bde_debug_occupancy(const char* kernel);
  * with host_out == NULL enables them, a later call copies n values back. */
 int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n);
 
-/* HIP-event timing of the tagged launches of subsequent bde_forward calls (bench.py's roofline):
- * names "forward", "head", "enc_conv", "gates_x", "lstm<l>" (one span per recurrent step launch),
- * "attn<l>", "decoder".  bde_profile_get synchronises on the recorded events. */
+/* HIP-event timing of the tagged launches of subsequent bde_forward calls (bench.py's roofline), one span per
+ * launch on the stream the launch goes to: "head", "enc_conv<l>", "gates_x<l>", "lstm<l>" (one per recurrent step),
+ * "merge<l>", "to_tok<l>", "winblock<l>", "chain_*<l>" (the kernels of the split attention path), "dec_up<j>",
+ * "dec_conv<j>", "pred"; and stage spans around them: "forward", "attn<l>", "decoder".  bde_profile_names lists what
+ * was recorded; bde_profile_get synchronises on the recorded events. */
 int bde_profile_reset(bde_model* m, int32_t enable);
+int bde_profile_names(bde_model* m, char* buf, int64_t buflen);
 int bde_profile_get(bde_model* m, const char* name, double* total_ms, int64_t* count);
 
 /* Event -> voxel grid.  xs, ys, ts, ps: device fp32 [N] (ts sorted ascending);

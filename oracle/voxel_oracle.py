@@ -36,6 +36,26 @@ def events_to_voxel(xs, ys, ts, ps, num_bins, sensor_size):
     return out
 
 
+def events_to_voxel_indexput(xs, ys, ts, ps, num_bins, sensor_size):
+    """The same binning with the reference's own operation sequence -- per bin one full pass over the events and one
+    `index_put_(accumulate=True)` into a zero image (event_utils.py:492-507 calling :360,371-375) -- on torch CPU
+    tensors.  This is the form bench.py times as the host baseline of the voxel path; pinned to the
+    same goldens as `events_to_voxel`."""
+    import torch
+    H, W = sensor_size
+    B = int(num_bins)
+    dt = ts[-1] - ts[0]                                                   # :489
+    t_norm = (ts - ts[0]) / dt * (B - 1)                                  # :490
+    xi, yi = xs.long(), ys.long()                                         # :371-372 (truncation)
+    bins = []
+    for b in range(B):
+        w = ps * torch.clamp(1.0 - torch.abs(t_norm - b), min=0.0)        # :494-495  max(0, 1 - |t - b|)
+        img = torch.zeros((H, W), dtype=torch.float32)                    # :360
+        img.index_put_((yi, xi), w, accumulate=True)                      # :375
+        bins.append(img)
+    return torch.stack(bins)                                              # :508
+
+
 def between_frames_voxels(xs, ys, ts, ps, event_idx, num_bins, sensor_size):
     """Voxel grids of consecutive windows from native event columns: the item assembly of
     BaseVoxelDataset.__getitem__ (data_loader/h5_dataset.py:213-226) on the columns DynamicH5Dataset.get_events

@@ -168,3 +168,12 @@ def test_recording_voxels_match_reference(name, case):
     assert v.shape == z[name].shape
     assert np.array_equal(v, z[name])
     assert not v[-1].any() and not v[-2].any()          # the 2-event and the empty window
+
+
+@pytest.mark.parametrize('name', ['n3', 'n1k_dups', 'n50k', 'edges'])
+def test_voxel_indexput_form_matches_reference(name):
+    """The operation-for-operation form bench.py times as the host baseline of the voxel path."""
+    z = np.load(os.path.join(GOLDEN, 'voxel.npz'))
+    xs, ys, ts, ps, size = voxel_case(name)
+    v = voxel_oracle.events_to_voxel_indexput(*[torch.from_numpy(a) for a in (xs, ys, ts, ps)], 5, size)
+    assert maxabs(v, z[name]) <= 1e-6
