@@ -1198,6 +1198,19 @@ static int check_dims(const bde_model* m, int T, int B, int H, int W) {
 static int forward_on(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
                       hipStream_t s);
 
+// The internal streams of the pipelined mode live as long as the process (one set per device, shared by the models
+// on it): the caller's allocator may hold them as the last user of a tensor (record_stream) long after a model is
+// gone, and recording on a destroyed stream faults.
+static int pipeline_stream(int slot, hipStream_t* out) {
+    static hipStream_t pool[BDE_MAX_DEVICES][bde_model::MAX_SLOTS] = {};
+    int d = 0;
+    BDE_HIP(hipGetDevice(&d));
+    BDE_REQUIRE(d >= 0 && d < BDE_MAX_DEVICES, "device %d", d);
+    if (!pool[d][slot]) BDE_HIP(hipStreamCreateWithFlags(&pool[d][slot], hipStreamNonBlocking));
+    *out = pool[d][slot];
+    return BDE_OK;
+}
+
 // Pipelined dispatch: call i runs on internal stream i%depth with workspace i%depth.  Inputs are ordered
 // after the caller's stream by an event; outputs are ordered back by bde_wait_outputs (or by the
 // next call that reuses the slot).
@@ -1209,7 +1222,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     }
     const int slot = (int)(m->ncalls++ % m->pipeline);
     if (!m->pstream[slot]) {
-        BDE_HIP(hipStreamCreateWithFlags(&m->pstream[slot], hipStreamNonBlocking));
+        BDE_TRY(pipeline_stream(slot, &m->pstream[slot]));
         BDE_HIP(hipEventCreateWithFlags(&m->pin[slot], hipEventDisableTiming));
         BDE_HIP(hipEventCreateWithFlags(&m->pout[slot], hipEventDisableTiming));
     }
@@ -1412,7 +1425,7 @@ void bde_destroy(bde_model* m) {
     for (int i = 0; i < bde_model::MAX_SLOTS; ++i) {
         if (m->pin[i]) (void)hipEventDestroy(m->pin[i]);
         if (m->pout[i]) (void)hipEventDestroy(m->pout[i]);
-        if (m->pstream[i]) (void)hipStreamDestroy(m->pstream[i]);
+        // (pstream[i] belongs to the per-device pool, pipeline_stream())
     }
     if (m->dev) (void)hipFree(m->dev);
     for (auto& sp : m->prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -1555,6 +1568,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
         for (const auto& w : m->wslots) n += w.graph_exec != nullptr;
         *value = n;
     } else if (k == "pipeline") *value = m->pipeline;
+    else if (k == "last_stream") *value = (int64_t)(uintptr_t)m->last_stream;   // internal stream of the latest pipelined call
     else if (k == "device") *value = m->device;
     else if (k == "winblock") *value = m->winblock;
     else if (k == "packed_numel") *value = m->dev_numel;

@@ -184,7 +184,15 @@ def pmc_traffic(span, avg_us):
             pmc = json.load(f)
     except Exception:
         return None, None
-    ent = pmc.get('spans', {}).get(span)
+    spans = pmc.get('spans', {})
+    ent = spans.get(span)
+    if ent is None:                                  # families sharing a kernel template ("gates_x*"): nearest duration
+        base = re.sub(r'\d+$', '', span)
+        for key, cands in spans.items():
+            if isinstance(cands, list) and base in key:
+                ent = min(cands, key=lambda e: abs((e.get('avg_us') or 0) - avg_us))
+    if isinstance(ent, list):
+        ent = min(ent, key=lambda e: abs((e.get('avg_us') or 0) - avg_us))
     if not ent:
         return None, None
     prov = {'file': os.path.relpath(PMC_FILE, REPO), 'kernel': ent.get('kernel'), 'dispatches': ent.get('dispatches'),

@@ -247,7 +247,7 @@ def test_bench_workload_matches_reference_in_serving_mode():
     z, meta = load_golden('e2e_bench_T16')
     cfg = canonical()
     m = build_model(cfg, formula_state_dict(cfg, meta['weight_seed']), 'cuda:0')
-    vox, n_events = bench_voxels(meta['T'], tuple(meta['sensor']), 'cuda:0', seed0=meta['seed'])
+    vox, n_events, _ = bench_voxels(meta['T'], tuple(meta['sensor']), 'cuda:0', seed0=meta['seed'])
     assert n_events == meta['T'] * meta['events_per_frame']
     inputs = [{'events': vox[t]} for t in range(meta['T'])]
     m.set_tuning('pipeline', 3)

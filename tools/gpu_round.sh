@@ -13,7 +13,7 @@ for mode in default pipeline1; do
   ARGS="--steps 6 --warmup 2 --no-cpu-baseline"; [ $mode = pipeline1 ] && ARGS="$ARGS --pipeline 1"
   rm -rf $R/gpurun_out/prof_${TAG}_$mode
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$mode -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_$mode.log 2>&1 || { tail -5 $R/gpurun_out/prof_${TAG}_$mode.log; exit 1; }
-  (cd $R && python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode > gpurun_out/${TAG}_${mode}_summary.txt; cp $(find gpurun_out/prof_${TAG}_$mode -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_${mode}_kernel_stats.csv)
+  (cd $R && NF=17; [ $mode = pipeline1 ] && NF=13; python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode $NF > gpurun_out/${TAG}_${mode}_summary.txt; cp $(find gpurun_out/prof_${TAG}_$mode -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_${mode}_kernel_stats.csv)
 done
 cd $R
 head -32 gpurun_out/${TAG}_pipeline1_summary.txt
