@@ -1,15 +1,22 @@
-# Builds the gfx950 shared library and the C oracle pieces.  hipcc cross-compiles without a GPU.
+# Builds the gfx950 shared library.  hipcc cross-compiles without a GPU.  Two translation units (the conv-shaped
+# kernels and everything else) compile in parallel: `make -j2`.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 LIB    = bde2vid_amd/libbde2vid.so
-SRC    = bde2vid_amd/csrc/bde_api.hip
+SRCS   = bde2vid_amd/csrc/bde_api.hip bde2vid_amd/csrc/conv_tu.hip
+OBJS   = $(SRCS:bde2vid_amd/csrc/%.hip=build/%.o)
 HDR    = $(wildcard bde2vid_amd/csrc/*.h) include/bde2vid.h
+FLAGS  = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -fvisibility=hidden -DBDE_BUILD
 
-all: $(LIB)
+all:
+	@$(MAKE) --no-print-directory -j2 $(LIB)
 
-$(LIB): $(SRC) $(HDR)
-	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function \
-	    -fvisibility=hidden -DBDE_BUILD -o $@ $(SRC)
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+build/%.o: bde2vid_amd/csrc/%.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(FLAGS) -c -o $@ $<
 
 clean:
-	rm -f $(LIB)
+	rm -rf build $(LIB)

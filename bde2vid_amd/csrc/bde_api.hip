@@ -28,6 +28,8 @@
 
 namespace bde {
 
+int conv_tu_occupancy(const char* kernel);   // conv_tu.hip
+
 std::string& last_error_ref() {
     static thread_local std::string e;
     return e;
@@ -1593,14 +1595,11 @@ int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n) {
 int bde_debug_occupancy(const char* kernel) {
     int nb = -1;
     std::string k(kernel ? kernel : "");
-    hipError_t e = hipErrorInvalidValue;
-    if (k == "lstm16_1_64") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 64, 1, false>, 256, 0);
-    else if (k == "lstm16_1_128_s2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<1, 128, 2, false>, 256, 0);
-    else if (k == "lstm16_2_32") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm16_step_kernel<2, 32, 1, false>, 256, 0);
-    else if (k == "token_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64));
-    else if (k == "conv_k3_m2n2") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_mfma_kernel<3, 1, 2, 2, 8, false, EPI_GENERIC, conv_maxi(3)>, 256, 42 * 1024);
-    if (e != hipSuccess) return -1;
-    return nb;
+    if (k == "token_fused") {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, token_fused_kernel<2>, 256, token_lds_bytes(64)) != hipSuccess) return -1;
+        return nb;
+    }
+    return conv_tu_occupancy(kernel);
 }
 
 int bde_profile_reset(bde_model* m, int32_t enable) {
@@ -1675,10 +1674,20 @@ int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t num
     return BDE_OK;
 }
 
+// 0 = tile-privatised binning (default), 1 = global float-atomic scatter (the first kernel; kept for A/B timing)
+static int& voxel_method_ref() { static int v = 0; return v; }
+int bde_voxel_method(int32_t method) {
+    BDE_REQUIRE(method == 0 || method == 1, "voxel method %d", method);
+    voxel_method_ref() = method;
+    return BDE_OK;
+}
+
 int bde_voxelize(const float* xs, const float* ys, const float* ts, const float* ps, int64_t N, int32_t num_bins,
                  int32_t H, int32_t W, float* grid, int32_t* oob_count, void* stream) {
     BDE_REQUIRE(grid && num_bins >= 1 && H >= 1 && W >= 1 && N >= 0, "bad argument");
     BDE_REQUIRE(N == 0 || (xs && ys && ts && ps), "null event array");
+    if (voxel_method_ref() == 0)
+        return voxel_tile_launch<false>(xs, ys, ts, ps, nullptr, nullptr, (long)N, 1, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
     return voxel_launch(xs, ys, ts, ps, nullptr, 1, (long)N, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
 }
 
@@ -1688,6 +1697,9 @@ int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const 
     BDE_REQUIRE(grids && offsets && nseg >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
     BDE_REQUIRE(xs && ys && ts && ps, "null event array");
     static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
+    if (voxel_method_ref() == 0)
+        return voxel_tile_launch<false>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nseg, num_bins, H, W, grids,
+                                        oob_count, (hipStream_t)stream);
     return voxel_launch(xs, ys, ts, ps, (const long*)offsets, nseg, (long)max_events_per_seg, num_bins, H, W, grids,
                         oob_count, (hipStream_t)stream);
 }
@@ -1698,8 +1710,28 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
     BDE_REQUIRE(grids && offsets && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
     BDE_REQUIRE(max_events_per_window <= 0 || (xs && ys && ts && ps), "null event column");
     static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
+    if (voxel_method_ref() == 0)
+        return voxel_tile_launch<true>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nwin, num_bins, H, W, grids,
+                                       oob_count, (hipStream_t)stream);
     return voxel_native_launch(xs, ys, ts, ps, (const long*)offsets, nwin, (long)max_events_per_window, num_bins, H, W, grids,
                                oob_count, (hipStream_t)stream);
+}
+
+int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, const int64_t* starts,
+                              const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H, int32_t W, float* grids,
+                              int32_t* oob_count, void* stream) {
+    BDE_REQUIRE(grids && starts && ends && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
+    return voxel_tile_launch<true>(xs, ys, ts, ps, (const long*)starts, (const long*)ends, 0, nwin, num_bins, H, W, grids, oob_count,
+                                   (hipStream_t)stream);
+}
+
+int bde_find_ts_index(const double* ts, int64_t n, const double* timestamps, int32_t nq, int64_t* out, void* stream) {
+    BDE_REQUIRE(out && nq >= 0 && n >= 0 && (n == 0 || ts) && (nq == 0 || timestamps), "bad argument");
+    if (nq == 0) return BDE_OK;
+    hipLaunchKernelGGL(find_ts_index_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, ts, (long)n, timestamps, nq,
+                       (long*)out);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
 }
 
 // ---- single sub-modules ----------------------------------------------------------------------

@@ -564,6 +564,7 @@ static int conv_launch_ks(ConvArgs a, int G, hipStream_t stream) {
     return conv_launch_t<KS, STRIDE, 1, 1, CK, false, EPI_GENERIC, CONV_MAXI>(a, G, stream);
 }
 
+#ifdef BDE_CONV_TU
 static int conv_launch_auto(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream) {
     if (KS == 5 && stride == 1) return conv_launch_ks<5, 1>(a, G, stream);
     if (KS == 5 && stride == 2) return conv_launch_ks<5, 2>(a, G, stream);
@@ -576,5 +577,7 @@ static int lstm_launch(ConvArgs a, hipStream_t stream) {
     a.row_tiles = cdiv(a.Wo, 32);
     return conv_launch_t<3, 1, 4, 1, LSTM_CK, true, EPI_LSTM, 4>(a, 2, stream);
 }
+
+#endif
 
 }  // namespace bde

@@ -255,7 +255,8 @@ static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launc
     return bnt == 2 ? conv_vec_launch_t<KS, STRIDE, 1, 2>(a, G, stream) : conv_vec_launch_t<KS, STRIDE, 1, 1>(a, G, stream);
 }
 
-static int conv_launch_best(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream) {
+#ifdef BDE_CONV_TU
+int conv_launch_best(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream) {
     bool done = false;
     if (tuning().conv_vec) {
         int st = BDE_OK;
@@ -267,5 +268,10 @@ static int conv_launch_best(int KS, int stride, const ConvArgs& a, int G, hipStr
     }
     return conv_launch_auto(KS, stride, a, G, stream);
 }
+
+#else
+// (defined in conv_tu.hip: the convolution kernels are compiled in a translation unit of their own)
+int conv_launch_best(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream);
+#endif
 
 }  // namespace bde

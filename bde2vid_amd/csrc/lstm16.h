@@ -294,7 +294,8 @@ static bool lstm16_wants_hc8(const ConvArgs& a) {
     return seg == 1 && wg16 < 640 && wg16 % 256 != 0 && (a.Cout / 4) % 8 == 0;
 }
 
-static int lstm16_launch(const ConvArgs& a, hipStream_t stream, bool hc8 = false) {
+#ifdef BDE_CONV_TU
+int lstm16_launch(const ConvArgs& a, hipStream_t stream, bool hc8 = false) {
     if (a.Cin % L16_CK != 0) return fail(BDE_ERR_UNSUPPORTED, "recurrent step: %d hidden channels is not a multiple of %d", a.Cin, L16_CK);
     int rows, pxw, seg;
     long wg16;
@@ -310,5 +311,9 @@ static int lstm16_launch(const ConvArgs& a, hipStream_t stream, bool hc8 = false
     if (rows == 1 && pxw == 128 && seg == 2) return lstm16_launch_t<1, 128, 2, false>(a, stream);
     return fail(BDE_ERR_ARG, "recurrent step: tile shape %dx%d (x%d segments) not built", rows, pxw, seg);
 }
+
+#else
+int lstm16_launch(const ConvArgs& a, hipStream_t stream, bool hc8 = false);   // conv_tu.hip
+#endif
 
 }  // namespace bde

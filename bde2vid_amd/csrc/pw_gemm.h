@@ -216,7 +216,8 @@ static int pw_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
 // Pick the decomposition of one pointwise GEMM launch: enough waves to cover the 1024 SIMDs,
 // as little reduction as possible.
 // (tuning().pw_force / pw_batched: mt*100 + nt*10 + ws overrides for the per-frame / T-batched launches)
-static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
+#ifdef BDE_CONV_TU
+int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
     if (const int f = tuning().pw_batched; f != 0 && (long)G * a.N > 4) {
         switch (f) {
             case 221: return pw_launch_t<2, 2, 1>(a, G, stream);
@@ -247,5 +248,9 @@ static int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream) {
     if (kpairs >= 32) return pw_launch_t<1, 1, 4>(a, G, stream);
     return pw_launch_t<1, 1, 1>(a, G, stream);
 }
+
+#else
+int pw_launch_auto(const ConvArgs& a, int G, hipStream_t stream);   // conv_tu.hip
+#endif
 
 }  // namespace bde

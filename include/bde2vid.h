@@ -153,6 +153,18 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
                         const int64_t* offsets, int32_t nwin, int64_t max_events_per_window, int32_t num_bins,
                         int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream);
 
+/* The same for arbitrary, possibly overlapping windows [starts[w], ends[w]) (device int64 [nwin] each): the k_events and
+ * t_seconds voxel methods with a sliding window (h5_dataset.py:277-302). */
+int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps,
+                              const int64_t* starts, const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H,
+                              int32_t W, float* grids, int32_t* oob_count, void* stream);
+/* Binning kernel behind all bde_voxelize* calls of the process: 0 (default) = a workgroup per (window, pixel tile)
+ * accumulates in LDS and stores the tile; 1 = one global float atomic per tap (kept for A/B timing). */
+int bde_voxel_method(int32_t method);
+/* DynamicH5Dataset.find_ts_index (h5_dataset.py:444-446 -> event_utils.py:10-28) for nq timestamps at once on the
+ * device-resident events/ts column (float64 [n], ascending): out[i] = the index the reference's bisection returns. */
+int bde_find_ts_index(const double* ts, int64_t n, const double* timestamps, int32_t nq, int64_t* out, void* stream);
+
 /* ---- single reference sub-modules (parity tests) ------------------------------------------- */
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream);
 /* RecurrentConv of level `level`, direction `dir` (0 forward_encoder, 1 backward_encoder) applied

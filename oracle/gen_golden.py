@@ -267,6 +267,46 @@ def gen_recording_voxels():
     print('voxel_recording', {k: v.shape for k, v in out.items()})
 
 
+REC_DATASET = dict(n=6000, height=36, width=48, nframes=12, seed=31)
+REC_METHODS = {
+    'between_frames': {'method': 'between_frames'},
+    't_seconds': {'method': 't_seconds', 't': 0.06, 'sliding_window_t': 0.02},
+    'k_events': {'method': 'k_events', 'k': 700, 'sliding_window_w': 200},
+}
+
+
+def gen_recording_dataset():
+    """The reference's own DynamicH5Dataset (data_loader/h5_dataset.py:398-455 on BaseVoxelDataset :45-396) run on a synthetic
+    recording held by oracle/fake_h5.File in place of h5py.File (h5py is not installed): event index tables of the three
+    voxel methods, find_ts_index on probe timestamps, and complete items (voxel grid, frame, dt, timestamp)."""
+    from bde2vid_amd.synth import synthetic_recording_with_frames
+    from oracle import fake_h5
+    D = ref_import.import_h5_dataset()
+    rec = synthetic_recording_with_frames(**REC_DATASET)
+    D.h5py.File = lambda path, mode='r': fake_h5.File(rec)
+    out = {}
+    probes = np.concatenate([rec['ts'][[0, 1, 7, 2999, 5999]], rec['frame_ts'], [rec['ts'][0] - 1.0, rec['ts'][-1] + 1.0],
+                             (rec['ts'][100:110] + rec['ts'][101:111]) / 2])
+    for name, vm in REC_METHODS.items():
+        ds = D.DynamicH5Dataset('synthetic.h5', num_bins=5, voxel_method=dict(vm))
+        out[name + '_indices'] = np.asarray(ds.event_indices, dtype=np.int64)
+        out[name + '_len'] = np.int64(len(ds))
+        if name == 'between_frames':
+            out['find_ts_index'] = np.asarray([ds.find_ts_index(float(t)) for t in probes], dtype=np.int64)
+            out['base_frame_indices'] = np.asarray(D.BaseVoxelDataset.compute_frame_indices(ds), dtype=np.int64)
+        idxs = list(range(min(len(ds), 6)))
+        items = [ds[i] for i in idxs]
+        out[name + '_events'] = np.stack([it['events'].numpy() for it in items])
+        out[name + '_dt'] = np.asarray([float(it['dt']) for it in items])
+        out[name + '_timestamp'] = np.asarray([float(it['timestamp']) for it in items])
+        if name == 'between_frames':
+            out[name + '_frame'] = np.stack([it['frame'].numpy() for it in items])
+    out['probes'] = probes
+    np.savez_compressed(os.path.join(OUT, 'rec_dataset.npz'), **out,
+                        meta=json.dumps(dict(recording=REC_DATASET, methods=REC_METHODS)))
+    print('rec_dataset', {k: getattr(v, 'shape', v) for k, v in out.items()})
+
+
 def gen_croper():
     Croper = ref_import.import_croper()
     res = {}
@@ -298,6 +338,7 @@ if __name__ == '__main__':
     gen_croper()
     gen_voxels()
     gen_recording_voxels()
+    gen_recording_dataset()
     gen_blocks()
     gen_e2e()
     gen_cfgA_sampled()

@@ -60,6 +60,28 @@ def import_event_utils():
     return EU
 
 
+def import_h5_dataset():
+    """The reference's data_loader.h5_dataset with the absent third-party modules it imports but does not need for the
+    index logic (h5py, cv2, skimage) replaced by empty modules."""
+    _prepare()
+
+    def stub(name):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+    for name in ('h5py', 'cv2', 'skimage', 'skimage.io'):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                stub(name)
+    if not hasattr(sys.modules['skimage'], 'io'):
+        sys.modules['skimage'].io = sys.modules['skimage.io']
+    import data_loader.h5_dataset as D
+    return D
+
+
 def import_croper():
     _prepare()
     from utils_func.inference_utils import Croper

@@ -1,0 +1,85 @@
+"""GPU parity of the file side of the data path (bde2vid_amd/recording.py, bde_find_ts_index, bde_voxelize_event_ranges)
+against what the reference's own DynamicH5Dataset returned for the same synthetic recording (tests/golden/rec_dataset.npz,
+oracle/gen_golden.py::gen_recording_dataset).  Index tables are exact; voxel grids differ only by the float summation order."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLDEN, maxabs
+from bde2vid_amd.synth import synthetic_recording_with_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def golden():
+    z = np.load(os.path.join(GOLDEN, 'rec_dataset.npz'))
+    meta = json.loads(str(z['meta']))
+    return z, meta, synthetic_recording_with_frames(**meta['recording'])
+
+
+@pytest.mark.parametrize('method', ['between_frames', 't_seconds', 'k_events'])
+def test_recording_matches_reference_dataset(golden, method):
+    from bde2vid_amd.recording import Recording
+    from oracle import fake_h5                         # an h5py.File stand-in (h5py is not installed in this image)
+    z, meta, rec = golden
+    ds = Recording(fake_h5.File(rec), num_bins=5, voxel_method=dict(meta['methods'][method]))
+    assert len(ds) == int(z[method + '_len'])
+    assert np.asarray(ds.event_indices).tolist() == z[method + '_indices'].tolist()
+    assert tuple(ds.sensor_resolution) == (36, 48) and ds.num_events == 6000 and ds.num_frames == 12
+    n = z[method + '_events'].shape[0]
+    grids = ds.voxels(range(n))
+    assert maxabs(grids, z[method + '_events']) <= 1e-4
+    for i in range(n):
+        it = ds[i]
+        assert maxabs(it['events'], z[method + '_events'][i]) <= 1e-4
+        assert float(it['dt']) == float(z[method + '_dt'][i])
+        assert float(it['timestamp']) == float(z[method + '_timestamp'][i])
+        if method == 'between_frames':
+            assert torch.equal(it['frame'].cpu(), torch.from_numpy(z['between_frames_frame'][i]))
+            assert it['flow'].shape == (2, 36, 48) and float(it['flow'].abs().max()) == 0.0
+
+
+def test_find_ts_index_is_the_reference_bisection(golden):
+    from bde2vid_amd.recording import Recording
+    z, meta, rec = golden
+    arrays = {k: v for k, v in rec.items() if k != 'event_idx'}      # a file without event_idx attributes
+    ds = Recording(arrays=arrays)
+    assert ds.find_ts_index(z['probes']).tolist() == z['find_ts_index'].tolist()
+    assert ds.find_ts_index(float(z['probes'][3])) == int(z['find_ts_index'][3])
+    # BaseVoxelDataset.compute_frame_indices (h5_dataset.py:261-275): frame windows from the timestamps alone
+    assert np.asarray(ds.event_indices).tolist() == z['base_frame_indices'].tolist()
+
+
+def test_out_of_range_item_raises_like_the_reference(golden):
+    from bde2vid_amd.recording import Recording
+    z, meta, rec = golden
+    ds = Recording(arrays=rec, voxel_method={'method': 'k_events', 'k': 700, 'sliding_window_w': 200})
+    last = len(ds) - 1
+    assert ds.event_indices[last][1] > ds.num_events        # the reference's table runs past the recording too
+    with pytest.raises(Exception, match='out of bounds'):
+        ds[last]
+    with pytest.raises(Exception, match='length of zero'):
+        Recording(arrays=rec, voxel_method={'method': 'k_events', 'k': 10 ** 7, 'sliding_window_w': 0})
+
+
+def test_tile_binning_equals_atomic_scatter():
+    """The tile-privatised kernel (default) against the global-atomic scatter on overlapping-free windows of a larger
+    recording, HD-sized sensor (several column tiles), windows with 0 and 2 events included."""
+    from bde2vid_amd import _lib
+    from bde2vid_amd.events import events_to_voxel_windows
+    from bde2vid_amd.synth import synthetic_recording
+    xs, ys, ts, ps, idx = synthetic_recording(300000, 720, 1280, 9, 5)
+    L = _lib.lib()
+    a = events_to_voxel_windows(xs, ys, ts, ps, idx, 5, sensor_size=(720, 1280))
+    _lib.check(L.bde_voxel_method(1))
+    try:
+        b = events_to_voxel_windows(xs, ys, ts, ps, idx, 5, sensor_size=(720, 1280))
+    finally:
+        _lib.check(L.bde_voxel_method(0))
+    assert maxabs(a, b) <= 1e-4
+    assert float(a[-2].abs().max()) == 0.0 and float(a[-3].abs().max()) == 0.0      # 2-event and empty windows
+    assert float(a.abs().sum()) > 0

@@ -177,3 +177,31 @@ def test_voxel_indexput_form_matches_reference(name):
     xs, ys, ts, ps, size = voxel_case(name)
     v = voxel_oracle.events_to_voxel_indexput(*[torch.from_numpy(a) for a in (xs, ys, ts, ps)], 5, size)
     assert maxabs(v, z[name]) <= 1e-6
+
+
+def test_recording_index_logic_matches_reference():
+    """oracle/recording_oracle.py against what the reference's own DynamicH5Dataset returned (tests/golden/rec_dataset.npz)."""
+    from oracle import recording_oracle as R
+    from bde2vid_amd.synth import synthetic_recording_with_frames
+    z = np.load(os.path.join(GOLDEN, 'rec_dataset.npz'))
+    meta = json.loads(str(z['meta']))
+    rec = synthetic_recording_with_frames(**meta['recording'])
+    ts = rec['ts']
+    assert [R.find_ts_index(ts, t) for t in z['probes']] == z['find_ts_index'].tolist()
+    assert R.frame_indices_from_attrs(rec['event_idx']) == z['between_frames_indices'].tolist()
+    assert R.frame_indices_from_timestamps(ts, rec['frame_ts']) == z['base_frame_indices'].tolist()
+    dur = ts[-1] - ts[0]
+    for name, vm in meta['methods'].items():
+        L = R.dataset_length(vm, rec['num_events'], rec['num_imgs'], dur)
+        assert L == int(z[name + '_len'])
+    vm = meta['methods']['t_seconds']
+    assert R.timeblock_indices(ts, vm, int(z['t_seconds_len'])) == z['t_seconds_indices'].tolist()
+    vm = meta['methods']['k_events']
+    assert R.k_indices(vm, int(z['k_events_len'])) == z['k_events_indices'].tolist()
+    # items: the voxel grids of the reference's __getitem__ against the numpy restatement of the binning
+    for name in meta['methods']:
+        idx = z[name + '_indices']
+        for k in range(z[name + '_events'].shape[0]):
+            i0, i1 = int(idx[k][0]), int(idx[k][1])
+            g = voxel_oracle.between_frames_voxels(rec['xs'], rec['ys'], ts, rec['ps'], [i0, i1], 5, (36, 48))[0]
+            assert maxabs(g, z[name + '_events'][k]) <= 1e-6
