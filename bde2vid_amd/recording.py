@@ -221,7 +221,8 @@ class Recording:
         voxel = self.voxels([index])[0]
         ts_0, ts_k, dt = self.item_times(index)
         if self.voxel_method['method'] == 'between_frames':
-            frame = torch.from_numpy(self.get_frame(index)).to(self.device).float().unsqueeze(0) / 255     # :370
+            # uint8 -> float / 255 on the host exactly as transform_frame does (:370; the GPU's division rounds 1 ulp apart)
+            frame = (torch.from_numpy(self.get_frame(index)).float().unsqueeze(0) / 255).to(self.device)
             flow = torch.zeros((2, frame.shape[-2], frame.shape[-1]), dtype=frame.dtype, device=self.device)
             return {'frame': frame, 'flow': flow, 'events': voxel,
                     'timestamp': torch.tensor(self.frame_ts[index], dtype=torch.float64),
