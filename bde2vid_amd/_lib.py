@@ -52,6 +52,9 @@ SIGNATURES = {
     'bde_voxelize_event_ranges': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'bde_voxel_method': (_I, [_I]),
     'bde_find_ts_index': (_I, [_P, _L, _P, _I, _P, _P]),
+    'bde_metric_mse': (_I, [_P, _P, _L, _I, _P, _P, _P]),
+    'bde_metric_ssim': (_I, [_P, _P, _I, _I, _I, C.c_double, _P, _P, _P]),
+    'bde_metric_scratch_doubles': (_I, [_I]),
     'bde_op_head': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'bde_op_recurrent_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     'bde_op_encoder_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),

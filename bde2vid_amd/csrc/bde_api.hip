@@ -25,6 +25,7 @@
 #include "attn_mfma.h"
 #include "conv_vec.h"
 #include "voxel.h"
+#include "metrics.h"
 
 namespace bde {
 
@@ -1733,6 +1734,19 @@ int bde_find_ts_index(const double* ts, int64_t n, const double* timestamps, int
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
+
+int bde_metric_mse(const float* a, const float* b, int64_t numel_per_image, int32_t N, double* scratch, double* out, void* stream) {
+    BDE_REQUIRE(a && b && scratch && out && numel_per_image >= 1 && N >= 1, "bad argument");
+    return metric_mse_launch(a, b, (long)numel_per_image, N, scratch, out, (hipStream_t)stream);
+}
+
+int bde_metric_ssim(const float* a, const float* b, int32_t H, int32_t W, int32_t N, double data_range, double* scratch, double* out,
+                    void* stream) {
+    BDE_REQUIRE(a && b && scratch && out && N >= 1, "bad argument");
+    BDE_REQUIRE(H >= 7 && W >= 7, "win_size 7 exceeds the image extent %dx%d (scikit-image raises here as well)", H, W);
+    return metric_ssim_launch(a, b, H, W, N, data_range, scratch, out, (hipStream_t)stream);
+}
+int32_t bde_metric_scratch_doubles(int32_t N) { return N * METRIC_BLOCKS; }
 
 // ---- single sub-modules ----------------------------------------------------------------------
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream) {

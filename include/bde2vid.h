@@ -165,6 +165,18 @@ int bde_voxel_method(int32_t method);
  * device-resident events/ts column (float64 [n], ascending): out[i] = the index the reference's bisection returns. */
 int bde_find_ts_index(const double* ts, int64_t n, const double* timestamps, int32_t nq, int64_t* out, void* stream);
 
+/* ---- quality metrics of eval_model's scoring loop (eval_models_seq.py:229-258), device-resident ----------------- */
+/* a, b: device fp32 [N][numel_per_image]; out: device fp64 [N], out[n] = mean((a-b)^2) of image n
+ * (F.mse_loss per frame, evaluate/metrics.py:42-43).  scratch: device fp64 [bde_metric_scratch_doubles(N)]. */
+int bde_metric_mse(const float* a, const float* b, int64_t numel_per_image, int32_t N, double* scratch, double* out,
+                   void* stream);
+/* a, b: device fp32 [N][H][W]; out[n] = skimage.metrics.structural_similarity(a[n], b[n]) as called at
+ * evaluate/metrics.py:58-63 (7x7 uniform window, K1 .01, K2 .03, sample covariance, float64; data_range = 2 reproduces
+ * the call without data_range on float images).  H, W >= 7. */
+int bde_metric_ssim(const float* a, const float* b, int32_t H, int32_t W, int32_t N, double data_range, double* scratch,
+                    double* out, void* stream);
+int32_t bde_metric_scratch_doubles(int32_t N);
+
 /* ---- single reference sub-modules (parity tests) ------------------------------------------- */
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream);
 /* RecurrentConv of level `level`, direction `dir` (0 forward_encoder, 1 backward_encoder) applied
