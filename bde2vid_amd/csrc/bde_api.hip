@@ -453,6 +453,7 @@ struct bde_model {
     Tuning tune;                  // launch-shape overrides (common.h), per model
     int lstm_hc8 = -1;            // recurrent step with 8-channel workgroups: -1 auto (lstm16_wants_hc8), 0 never, 1 always
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
+    int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -748,6 +749,8 @@ struct ConvCall {
     long in_gs = 0, out_gs = 0;  // group strides (0 = shared input)
     int mask_w = 0, mask_pt = 0, mask_pl = 0;
     int cout_rows = -1;          // override (kvall uses all rows)
+    const float* pred_head = nullptr;   // fused predI (conv_mfma.h): set pred_out to enable
+    float* pred_out = nullptr;
 };
 
 static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
@@ -784,6 +787,13 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.res1_gs = a.res2_gs = cc.out_gs;
     a.w_gs = pl.w_sz;
     a.bias_gs = pl.Cout;
+    if (cc.pred_out) {
+        a.pred_w = m->P(m->predw_off);
+        a.pred_b = m->P(m->predb_off);
+        a.pred_head = cc.pred_head;
+        a.pred_out = cc.pred_out;
+        a.pred_sigmoid = m->cfg.activation;
+    }
     if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
     return conv_launch_best(pl.KS, cc.stride, a, pl.G, s);
 }
@@ -1168,8 +1178,12 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
 }
 
 // UpsampleConvLayer of decoder j on N frames [Cin][Hs][Ws] (+ skip): upsample kernel, then a plain conv.
+// predI + the output activation ride in the conv's epilogue when one workgroup holds every output channel of a pixel
+// (Cout <= 64: the 32 channels of the canonical last decoder are one MFMA row tile)
+static bool pred_fusable(const bde_model* m) { return m->cfg.basechannels <= 64 && m->fuse_pred; }
+
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
-                       hipStream_t s) {
+                       hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr) {
     const PackedLayer& pl = m->dec[j];
     { ProfScope ps(m, pname("dec_up", j), s); BDE_TRY(upsample2x_sum(in, skip, m->W().up, Hs, Ws, (long)N * pl.Cin, s)); }
     ConvCall d;
@@ -1180,6 +1194,8 @@ static int run_decoder(bde_model* m, int j, const float* in, const float* skip, 
     d.Hs = 2 * Hs;
     d.Ws = 2 * Ws;
     d.act = ACT_RELU6;
+    d.pred_head = pred_head;
+    d.pred_out = pred_out;
     ProfScope ps(m, pname("dec_conv", j), s);
     return run_conv(m, d, s);
 }
@@ -1311,10 +1327,14 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
             const long in_fs = (long)mm->cout(l) * (H_ >> (l + 1)) * (W_ >> (l + 1));
             const long out_fs = (long)mm->cin(l) * (H_ >> l) * (W_ >> l);
             ProfScope ps(mm, "decoder", st);
+            const bool fuse = (j == L_ - 1) && pred_fusable(mm);       // V5.py:195-197 in the last conv's epilogue
             BDE_TRY(run_decoder(mm, j, x, w.merged[l] + (long)f0 * in_fs, w.dec[j] + (long)f0 * out_fs, nf,
-                                H_ >> (l + 1), W_ >> (l + 1), st));
+                                H_ >> (l + 1), W_ >> (l + 1), st,
+                                fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
+                                fuse ? w.out + (long)f0 * H_ * W_ : nullptr));
             x = w.dec[j] + (long)f0 * out_fs;
         }
+        if (pred_fusable(mm)) return BDE_OK;
         const long total = (long)nf * H_ * W_;
         long blocks = std::min<long>(cdivl(total, 256), 4096);
         ProfScope ps(mm, "pred", st);
@@ -1547,6 +1567,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         m->winblock = (int)value;
         return BDE_OK;
     }
+    if (std::string(key) == "fuse_pred") { m->fuse_pred = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { m->tune.pw_batched = (int)value; return BDE_OK; }
     if (std::string(key) == "pw_force") { m->tune.pw_force = (int)value; return BDE_OK; }
@@ -1664,6 +1685,7 @@ int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t num
     } else if (nm.rfind("dec", 0) == 0) {
         int j = atoi(nm.c_str() + 3);
         BDE_REQUIRE(j >= 0 && j < m->L, "decoder %d", j);
+        BDE_REQUIRE(!(j == m->L - 1 && pred_fusable(m)), "dec%d is not materialised: predI is fused into its conv (set_tuning fuse_pred 0)", j);
         const int l = m->L - 1 - j;
         src = ws.dec[j];
         n = TB * m->cin(l) * (long)(ws.H >> l) * (ws.W >> l);

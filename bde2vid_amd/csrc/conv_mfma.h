@@ -64,6 +64,13 @@ struct ConvArgs {
     float* cstate;       // [G][N][Ch][HW]    cell state, updated in place
     long gx_gs, gx_ns, c_gs, c_ns;
     int first;           // 1: h_prev == 0 -> skip the contraction entirely
+    // ---- fused predI (V5.py:195-197): when pred_out is set and one workgroup holds all Cout rows of a pixel, the
+    // epilogue emits act(sum_co pred_w[co] * (y[co] + pred_head[co]) + pred_b) per pixel INSTEAD of storing y
+    const float* pred_w;     // [Cout]
+    const float* pred_b;     // [1]
+    const float* pred_head;  // [N][Cout][Ho*Wo] or nullptr
+    float* pred_out;         // [N][Ho*Wo]
+    int pred_sigmoid;
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU
@@ -115,6 +122,31 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
             bv[m][rr] = biasg[co];
             sv[m][rr] = want_ln ? a.lnsum[co] : 0.f;
         }
+    if (a.pred_out != nullptr) {
+        // rows of this lane: acc_row(rr, lane); the other 16 rows of a pixel sit in lane ^ 32
+        const float* hb = a.pred_head ? a.pred_head + (long)n * a.Cout * HW : nullptr;
+        float* po = a.pred_out + (long)n * HW;
+        const float pb = a.pred_b[0];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = min(pix[t], p_end - 1);
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int co = m * 32 + acc_row(r0 + rr, lane);
+                    if (co >= a.Cout) continue;
+                    float v = act_apply(fin[m][t][rr] + bv[m][rr], a.act);
+                    if (hb) v += hb[(long)co * HW + p];
+                    s += a.pred_w[co] * v;
+                }
+            s += __shfl_xor(s, 32);
+            s += pb;
+            if ((lane >> 5) == 0 && pix[t] < p_end) po[p] = a.pred_sigmoid ? 1.f / (1.f + expf(-s)) : s;
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int p = pix[t];
