@@ -22,6 +22,7 @@
 #include "token_fused.h"
 #include "lstm16.h"
 #include "winblock.h"
+#include "wideblock.h"
 #include "attn_mfma.h"
 #include "conv_vec.h"
 #include "voxel.h"
@@ -259,6 +260,22 @@ static long pack16(Arena& ar, const float* w, int rows, int K) {
     return off;
 }
 
+// The same rows four k-steps per 16-byte load for wideblock.h: [co16 tile][k/16][64 lanes][4],
+// lane l, element j = W[tile*16 + (l&15)][kg*16 + 4*j + (l>>4)]; K must be a multiple of 16.
+static long pack16x4(Arena& ar, const float* w, int rows, int K) {
+    const int nct = cdiv(rows, 16), nkg = K / 16;
+    const long off = ar.alloc((long)nct * nkg * 256);
+    float* dst = ar.host.data() + off;
+    for (int ct = 0; ct < nct; ++ct)
+        for (int kg = 0; kg < nkg; ++kg)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 4; ++j) {
+                    const int r = ct * 16 + (l & 15), k = kg * 16 + 4 * j + (l >> 4);
+                    dst[((long)ct * nkg + kg) * 256 + l * 4 + j] = r < rows ? w[(long)r * K + k] : 0.f;
+                }
+    return off;
+}
+
 // Weight fragments of the recurrent step kernel (lstm16.h):
 // [hidden16 block][chunk of 8 channels][tap][k4][64 lanes][gate], lane l = W[gate*Ch + hb*16 + (l&15)][chunk*8 + k4*4 + (l>>4)][tap]
 // (the four gate fragments of a lane are adjacent: one 16-byte LDS read fetches them).
@@ -376,6 +393,7 @@ static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& g
 struct AttnBlock {
     PackedLayer qkv, proj, fc1, fc2;
     long proj16 = -1, fc1_16 = -1, fc2_16 = -1, qkv16 = -1;   // 16x16x4 packings for token_fused.h
+    long projW = -1, fc1W = -1, fc2W = -1, qkvW = -1;         // four-k-steps-per-load packings for wideblock.h
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -384,6 +402,7 @@ struct AttnLevel {
     int depth = 0, C = 0;
     std::vector<AttnBlock> blocks;
     PackedLayer kvall;      // rows = depth*2C: K|V of every block for a non-query frame
+    long kvallW = -1;       // the same rows packed for wideblock.h
 };
 
 struct Workspace {
@@ -454,6 +473,7 @@ struct bde_model {
     int lstm_hc8 = -1;            // recurrent step with 8-channel workgroups: -1 auto (lstm16_wants_hc8), 0 never, 1 always
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
+    int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -692,6 +712,12 @@ static int build_packed(bde_model* m) {
             fc2.w.assign(w2, w2 + (size_t)C * hid);
             fc2.bias.assign(b2b, b2b + C);
             ab.fc2 = pack_layer(ar, {&fc2}, false);
+            if (C % 64 == 0 && hd == 16) {
+                ab.projW = pack16x4(ar, proj.w.data(), C, C);
+                ab.fc1W = pack16x4(ar, fc1.w.data(), hid, C);
+                ab.fc2W = pack16x4(ar, fc2.w.data(), C, hid);
+                ab.qkvW = pack16x4(ar, qkv.w.data(), 3 * C, C);
+            }
             if (C % 16 == 0 && token_lds_bytes(C) <= 150 * 1024) {
                 ab.proj16 = pack16(ar, proj.w.data(), C, C);
                 ab.fc1_16 = pack16(ar, fc1.w.data(), hid, C);
@@ -700,6 +726,7 @@ static int build_packed(bde_model* m) {
             }
         }
         al.kvall = pack_layer(ar, {&kvall}, false);
+        if (C % 64 == 0 && hd == 16) al.kvallW = pack16x4(ar, kvall.w.data(), kvall.rows, C);
     }
     for (int j = 0; j < L; ++j) {
         const int cin = m->cout(L - 1 - j), cout = m->cin(L - 1 - j);
@@ -829,6 +856,7 @@ static int ws_alloc(Workspace& ws, float** p, long numel) {
 }
 
 static bool winblock_ok(const bde_model* m, int l);
+static bool wide_ok(const bde_model* m, int l);
 
 static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     Workspace& ws = m->W();
@@ -845,6 +873,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     long max_attn = 0;
     for (int l = 0; l < L; ++l) {
         const long C = m->cout(l), hw = (long)(H >> (l + 1)) * (W >> (l + 1));
+        const long hwp = cdivl(hw, 16) * 16;              // token tiles of 16 (wideblock.h)
         BDE_TRY(ws_alloc(ws, &ws.xenc[l], 2 * TB * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.gx[l], 2 * TB * 4 * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.hseq[l], 2 * TB * C * hw));
@@ -855,12 +884,18 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
                 // one-launch blocks recompute the neighbours' K|V: only the token-major twin of merged is staged
                 // (the K|V stacks of the split path are 71 GB at 1280x720, T = 64)
                 BDE_TRY(ws_alloc(ws, &ws.mergedT[l], TB * C * hw));
+            } else if (wide_ok(m, l)) {
+                // fragment-layout twin of merged (token tiles of 16) + token-major K|V stacks and first-block q|k|v
+                BDE_TRY(ws_alloc(ws, &ws.mergedT[l], TB * C * hwp));
+                BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
+                BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
+                BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
             } else {
                 BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
                 BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
                 BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
             }
-            max_attn = std::max(max_attn, (long)B * C * hw);
+            max_attn = std::max(max_attn, (long)B * C * hwp);
         }
         const int j = L - 1 - l;   // decoder j writes the map of level (L-1-j)'s input resolution
         BDE_TRY(ws_alloc(ws, &ws.dec[j], TB * m->cin(l) * (long)(H >> l) * (W >> l)));
@@ -1120,6 +1155,99 @@ static int run_attention_frame_win(bde_model* m, int l, const float* const* fram
     return BDE_OK;
 }
 
+static bool wide_ok(const bde_model* m, int l) {
+    const AttnLevel& al = m->attn[l];
+    return m->wide && al.depth > 0 && !winblock_ok(m, l) && al.kvallW >= 0 && al.blocks[0].qkvW >= 0 &&
+           m->cfg.frame_num * ATT_TOK <= 160;
+}
+
+// One GEMM of the wide chain (wideblock.h): x FRAG16 [B][ntile][K/16][256] -> token-major or FRAG16
+static int run_tokgemm(bde_model* m, const char* span, int l, long w_off, const PackedLayer& pl, int M, int K, const float* x, int B,
+                       long HW, float* out_tok, float* out_frag, int act, const float* res, const float* addres, float* out_nchw,
+                       int mask_w, int mask_pt, int mask_pl, long row_off, hipStream_t s) {
+    TokGemmArgs a;
+    memset(&a, 0, sizeof a);
+    const int ntile = (int)cdivl(HW, 16);
+    a.x = x;
+    a.w = m->P(w_off) + row_off / 16 * (K / 16) * 256;
+    a.bias = m->P(pl.b_off) + row_off;
+    a.lnsum = pl.s_off >= 0 ? m->P(pl.s_off) + row_off : nullptr;
+    a.out_tok = out_tok;
+    a.out_frag = out_frag;
+    a.out_nchw = out_nchw;
+    a.res = res;
+    a.addres = addres;
+    a.x_bs = (long)ntile * 16 * K;
+    a.out_bs = out_tok ? HW * M : (long)ntile * 16 * M;
+    a.res_bs = a.addres_bs = (long)ntile * 16 * M;
+    a.nchw_bs = HW * M;
+    a.K = K; a.M = M; a.HW = (int)HW; a.ntile = ntile;
+    a.act = act;
+    a.mask_w = mask_w; a.mask_pt = mask_pt; a.mask_pl = mask_pl;
+    ProfScope ps(m, pname(span, l), s);
+    return tokgemm_launch(a, B, s);
+}
+
+// DFrameAttention + refinement for one target frame on the wide chain.  Everything FRAG16 / token-major:
+//   xq       : query frame, FRAG16 [B][ntile][C/16][256]
+//   kvslot[d]: token-major K|V stack [B][HW][depth*2C] of slot d's frame (nullptr = zero frame; ignored for q_idx)
+//   addres   : FRAG16 tensor added to the result (merged[t]) or nullptr;   out: FRAG16;   out_nchw: optional [B][C][HW]
+//   qkv_first: token-major q|k|v [B][HW][3C] of block blk0 for xq if already computed (batched over T)
+static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const float* const* kvslot, const float* addres, float* out,
+                                    float* out_nchw, int B, int H, int W, int blk0, int nblk, const float* qkv_first, hipStream_t s) {
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->W();
+    const AttnLevel& al = m->attn[l];
+    const int C = al.C, D = c.frame_num;
+    const long HW = (long)H * W;
+    const int ph = (7 - H % 7) % 7, pw = (7 - W % 7) % 7;   // DTransformer.py:260-263
+    const int pt = ph / 2, plft = pw / 2;
+    const int ntile = (int)cdivl(HW, 16);
+    const float* x = xq;
+    for (int i = blk0; i < blk0 + nblk; ++i) {
+        const AttnBlock& ab = al.blocks[i];
+        const bool dil = (i % 2) == 1;                       // DTransformer.py:362
+        const bool last = (i == blk0 + nblk - 1);
+        const float* qkv = ws.qkv;
+        if (i == blk0 && qkv_first) qkv = qkv_first;
+        else BDE_TRY(run_tokgemm(m, "wide_qkv", l, ab.qkvW, ab.qkv, 3 * C, C, x, B, HW, ws.qkv, nullptr, ACT_NONE, nullptr, nullptr,
+                                 nullptr, 0, 0, 0, 0, s));
+        AttnTokArgs a;
+        memset(&a, 0, sizeof a);
+        a.q = qkv;
+        a.q_bs = HW * 3 * C;
+        a.q_ld = 3 * C;
+        for (int d = 0; d < D; ++d) {
+            if (d == c.q_idx) {
+                a.kv[d] = qkv; a.kv_bs[d] = HW * 3 * C; a.kv_ld[d] = 3 * C; a.k_off[d] = C; a.v_off[d] = 2 * C;
+            } else if (kvslot[d]) {
+                a.kv[d] = kvslot[d]; a.kv_bs[d] = HW * al.depth * 2 * C; a.kv_ld[d] = al.depth * 2 * C;
+                a.k_off[d] = i * 2 * C; a.v_off[d] = i * 2 * C + C;
+            } else {
+                a.kv[d] = nullptr;
+            }
+        }
+        a.kvpad = m->P(ab.kvpad_off);
+        a.biasT = m->P(ab.bias_off);
+        a.out = ws.ao;
+        a.out_bs = (long)ntile * 16 * C;
+        a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw;
+        a.pt = pt; a.pl = plft; a.nWw = (W + pw) / 7; a.dilated = dil ? 1 : 0; a.ntile = ntile;
+        { ProfScope ps(m, pname("wide_core", l), s); BDE_TRY(attn_tok16_launch(a, B, s)); }
+        float* dst = (last && out) ? out : (x == ws.xa ? ws.xb : ws.xa);     // out == nullptr: the caller only wants out_nchw
+        // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only; DTransformer.py:299, 79-82)
+        BDE_TRY(run_tokgemm(m, "wide_proj", l, ab.projW, ab.proj, C, C, ws.ao, B, HW, nullptr, ws.x1, ACT_NONE, x, nullptr, nullptr,
+                            dil ? W : 0, pt, plft, 0, s));
+        // x2 = x1 + fc2(GELU(fc1(LN(x1))))  (+ merged[t] after the last block; DTransformer.py:279-283,304, V5.py:166)
+        BDE_TRY(run_tokgemm(m, "wide_mlp_in", l, ab.fc1W, ab.fc1, 4 * C, C, ws.x1, B, HW, nullptr, ws.hid, ACT_GELU, nullptr, nullptr,
+                            nullptr, 0, 0, 0, 0, s));
+        BDE_TRY(run_tokgemm(m, "wide_mlp_out", l, ab.fc2W, ab.fc2, C, 4 * C, ws.hid, B, HW, nullptr, dst, ACT_NONE, ws.x1,
+                            last ? addres : nullptr, last ? out_nchw : nullptr, 0, 0, 0, 0, s));
+        x = dst;
+    }
+    return BDE_OK;
+}
+
 typedef int (*FrameDoneFn)(bde_model* m, int t, void* ctx);
 static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, hipStream_t s,
                                FrameDoneFn on_frame = nullptr, void* ctx = nullptr) {
@@ -1150,6 +1278,34 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
     for (int d = 0; d < D; ++d) {
         if (d == c.q_idx) continue;
         if (c.buffer_index[d] >= 0) need_un = true; else need_ref = true;
+    }
+    if (wide_ok(m, l)) {
+        const int ntile = (int)cdivl(HW, 16);
+        const long ffs = (long)B * ntile * 16 * C;           // FRAG16 frame stride
+        const long q0fs = (long)B * HW * 3 * C;
+        { ProfScope ps(m, pname("to_frag", l), s); BDE_TRY(nchw_to_frag(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s)); }
+        if (need_un)
+            BDE_TRY(run_tokgemm(m, "wide_kv_all", l, al.kvallW, al.kvall, al.depth * 2 * C, C, ws.mergedT[l], T * B, HW, ws.kvun[l],
+                                nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+        BDE_TRY(run_tokgemm(m, "wide_qkv_all", l, al.blocks[0].qkvW, al.blocks[0].qkv, 3 * C, C, ws.mergedT[l], T * B, HW, ws.qkv0[l],
+                            nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+        for (int t = 0; t < T; ++t) {
+            const float* kvslot[BDE_MAX_FRAMES];
+            for (int d = 0; d < D; ++d) {
+                const int f = t + c.buffer_index[d];
+                if (d == c.q_idx || f < 0 || f >= T) kvslot[d] = nullptr;
+                else if (f < t) kvslot[d] = ws.kvref[l] + (long)f * kvfs;      // refined (V5.py:166-169)
+                else kvslot[d] = ws.kvun[l] + (long)f * kvfs;
+            }
+            float* mtF = ws.mergedT[l] + (long)t * ffs;
+            BDE_TRY(run_attention_frame_wide(m, l, mtF, kvslot, mtF, mtF, ws.merged[l] + (long)t * fs, B, H, W, 0, al.depth,
+                                             ws.qkv0[l] + (long)t * q0fs, s));
+            if (need_ref && t + 1 < T)
+                BDE_TRY(run_tokgemm(m, "wide_kv", l, al.kvallW, al.kvall, al.depth * 2 * C, C, mtF, B, HW, ws.kvref[l] + (long)t * kvfs,
+                                    nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+            if (on_frame) BDE_TRY(on_frame(m, t, ctx));
+        }
+        return BDE_OK;
     }
     // K|V of every block for the still-unrefined frames, all T at once
     if (need_un) {
@@ -1567,6 +1723,12 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         m->winblock = (int)value;
         return BDE_OK;
     }
+    if (std::string(key) == "wide") {
+        if (m->wide != (int)value)
+            for (auto& w : m->wslots) w.release();
+        m->wide = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "fuse_pred") { m->fuse_pred = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { m->tune.pw_batched = (int)value; return BDE_OK; }
@@ -1595,6 +1757,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "last_stream") *value = (int64_t)(uintptr_t)m->last_stream;   // internal stream of the latest pipelined call
     else if (k == "device") *value = m->device;
     else if (k == "winblock") *value = m->winblock;
+    else if (k == "wide") *value = m->wide;
     else if (k == "packed_numel") *value = m->dev_numel;
     else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
     return BDE_OK;
@@ -1862,6 +2025,24 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
     }
     const long kvfs = (long)B * al.depth * 2 * al.C * HW;
     const float* kvslot[BDE_MAX_FRAMES];
+    if (wide_ok(m, level)) {
+        Workspace& w = m->W();
+        const int C = al.C;
+        const long ffs = (long)B * cdivl(HW, 16) * 16 * C;
+        for (int d = 0; d < D; ++d) {
+            kvslot[d] = nullptr;
+            if (bufs[d] == nullptr) continue;
+            float* fr = w.mergedT[level] + (long)d * ffs;
+            BDE_TRY(nchw_to_frag(bufs[d], fr, B, C, (int)HW, s));
+            if (d == c.q_idx) continue;
+            float* dst = w.kvun[level] + (long)d * kvfs;
+            BDE_TRY(run_tokgemm(m, "wide_kv", level, al.kvallW, al.kvall, al.depth * 2 * C, C, fr, B, HW, dst, nullptr, ACT_NONE, nullptr,
+                                nullptr, nullptr, 0, 0, 0, 0, s));
+            kvslot[d] = dst;
+        }
+        float* qf = w.mergedT[level] + (long)c.q_idx * ffs;
+        return run_attention_frame_wide(m, level, qf, kvslot, nullptr, nullptr, out, B, H, W, first_block, nblocks, nullptr, s);
+    }
     for (int d = 0; d < D; ++d) {
         kvslot[d] = nullptr;
         if (d == c.q_idx || bufs[d] == nullptr) continue;

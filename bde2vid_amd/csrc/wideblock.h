@@ -1,0 +1,412 @@
+// Temporal window attention for WIDE levels (head_dim 16: 256 channels / 16 heads at level 2 of the canonical config),
+// where a frame is only a few hundred tokens (23 x 30 at 184 x 240) and the five launches of a block sit on the sequential
+// chain of V5.py:154-169.  The split path (pw_gemm.h + attn_mfma.h) ran each of them in 10-13.5 us for < 1 us of matrix
+// work: NCHW planes make every operand fetch a gather of 28-byte runs, and every wave fetched its operands with dword
+// loads.  Here the chain keeps its activations in the layout the matrix cores consume:
+//
+//   FRAG16   [token tile of 16][channel group of 16][64 lanes][4]:  lane (col, g4), element j  =  x[token 16*tile + col]
+//            [channel 16*group + 4*j + g4] -- i.e. the tensor IS the sequence of B fragments of v_mfma_f32_16x16x4_f32,
+//            four k-steps per 16-byte load, 1 KiB per wave instruction, no LDS staging and no transposition anywhere.
+//            The D fragments of the producing GEMM land in it with four 256-byte stores per 16 x 16 tile.
+//   token-major [token][channels] for q|k|v, which the attention core gathers per window token (64 contiguous bytes per
+//            head instead of 16 scattered dwords).
+//
+//   tokgemm_kernel<MT, NT, KSPLIT>   out = epilogue(W x): weights pre-packed in the same four-k-steps-per-load order;
+//            LayerNorm folded as in pw_gemm.h (Linear(LN(x)) = rstd (W'x - mu s) + b', statistics from the streamed B
+//            fragments); epilogues: token-major store (q|k|v, K|V stacks) or FRAG16 store with GELU / residual /
+//            dilated-coverage mask / merged[t] / a second NCHW copy for the decoder.
+//   attn_tok16_kernel   softmax(q k^T + bias) v per (window, head) on the matrix cores as attn_mfma.h, reading token-major
+//            q|k|v with 16-byte loads and writing its output straight into FRAG16.
+//
+// Restates DTransformer.py:165-207 (WindowAttention3D), :254-306 (SwinTransformerBlock3D) and :19-37 (Mlp) exactly as the
+// split path does (same folded weights, same bias tables, same padding / dilation rules).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "attn.h"
+#include "common.h"
+#include "conv_mfma.h"
+#include "token_fused.h"
+
+namespace bde {
+
+typedef float wf4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ __forceinline__ long frag16_index(long tile, int ngroups, int channel, int col) {
+    // element (token 16*tile + col, channel) of a FRAG16 tensor with `ngroups` = C / 16 channel groups
+    const int grp = channel >> 4, j = (channel >> 2) & 3, g4 = channel & 3;
+    return ((tile * ngroups + grp) * 64 + (col + 16 * g4)) * 4 + j;
+}
+
+// [N][C][HW] planes -> FRAG16 [N][ntile][C/16][256]; tokens past HW are zero
+__global__ __launch_bounds__(256) void nchw_to_frag_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW,
+                                                           int ntile) {
+    const int tile = blockIdx.x, grp = blockIdx.y;
+    const long n = blockIdx.z;
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;          // 4 waves = 4 elements j of a lane's float4
+    const int col = lane & 15, g4 = lane >> 4;
+    const int tok = tile * 16 + col, ch = grp * 16 + 4 * j + g4;
+    const float v = (tok < HW && ch < C) ? in[(n * C + ch) * HW + tok] : 0.f;
+    out[((n * ntile + tile) * (C / 16) + grp) * 256 + lane * 4 + j] = v;
+}
+static int nchw_to_frag(const float* in, float* out, int N, int C, int HW, hipStream_t s) {
+    const int ntile = cdiv(HW, 16);
+    hipLaunchKernelGGL(nchw_to_frag_kernel, dim3(ntile, C / 16, N), dim3(256), 0, s, in, out, C, HW, ntile);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+// FRAG16 -> [N][C][HW] planes (the op-level entry point hands results back as NCHW)
+__global__ __launch_bounds__(256) void frag_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW,
+                                                           int ntile) {
+    const int tile = blockIdx.x, grp = blockIdx.y;
+    const long n = blockIdx.z;
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int col = lane & 15, g4 = lane >> 4;
+    const int tok = tile * 16 + col, ch = grp * 16 + 4 * j + g4;
+    if (tok < HW && ch < C) out[(n * C + ch) * HW + tok] = in[((n * ntile + tile) * (C / 16) + grp) * 256 + lane * 4 + j];
+}
+static int frag_to_nchw(const float* in, float* out, int N, int C, int HW, hipStream_t s) {
+    const int ntile = cdiv(HW, 16);
+    hipLaunchKernelGGL(frag_to_nchw_kernel, dim3(ntile, C / 16, N), dim3(256), 0, s, in, out, C, HW, ntile);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+struct TokGemmArgs {
+    const float* x;        // FRAG16 [B][ntile][K/16][256]
+    const float* w;        // packed [M/16][K/16][256]: lane l, element j = W[16*rt + (l&15)][16*kg + 4*j + (l>>4)]
+    const float* bias;     // [M]
+    const float* lnsum;    // [M] row sums of the LayerNorm-folded weights, nullptr = no LayerNorm
+    float* out_tok;        // token-major [B][HW][M]                       (one of out_tok / out_frag)
+    float* out_frag;       // FRAG16 [B][ntile][M/16][256]
+    float* out_nchw;       // optional second copy of the FRAG16 result as [B][M][HW]
+    const float* res;      // optional FRAG16 residual, shape of out_frag
+    const float* addres;   // optional second FRAG16 residual (merged[t], V5.py:166)
+    long x_bs, out_bs, res_bs, addres_bs, nchw_bs;     // batch strides (elements)
+    int K, M, HW, ntile;
+    int act;               // ACT_NONE | ACT_GELU
+    int mask_w, mask_pt, mask_pl;    // dilated-window coverage mask (DTransformer.py:79-82): uncovered pixels get the residuals only
+};
+
+// A wave computes MT row tiles x NT token tiles over 1/KSPLIT of K.  KSPLIT == 1: the four waves of a workgroup take
+// four consecutive groups of MT row tiles for the same tokens (the B fragments of three of them are L1 hits);
+// KSPLIT == 4: they take the four quarters of K of the same tiles and meet in LDS.
+template <int MT, int NT, int KSPLIT>
+__global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
+    static_assert(KSPLIT == 1 || KSPLIT == 4, "");
+    constexpr int U = 4;                                   // channel groups (of 16) fetched per batch
+    __shared__ float red[KSPLIT == 4 ? 3 * MT * NT * 256 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g4 = lane >> 4, col = lane & 15;
+    const int b = blockIdx.z;
+    const int ngk = a.K >> 4, ngm = a.M >> 4;
+    const int rt0 = (KSPLIT == 1 ? (blockIdx.y * 4 + wave) : blockIdx.y) * MT;
+    const int tt0 = blockIdx.x * NT;
+    if (KSPLIT == 1 && rt0 >= ngm) return;
+    const int kq = ngk / KSPLIT;                           // channel groups of this wave
+    const int kg0 = KSPLIT == 1 ? 0 : wave * kq;
+
+    const wf4* xp[NT];
+    const wf4* wp[MT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = min(tt0 + t, a.ntile - 1);
+        xp[t] = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)tile * ngk + kg0) * 64 + lane;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int rt = min(rt0 + m, ngm - 1);
+        wp[m] = reinterpret_cast<const wf4*>(a.w) + ((long)rt * ngk + kg0) * 64 + lane;
+    }
+    f32x4 acc[MT][NT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t][0] = acc[m][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.f;
+    const bool want_ln = a.lnsum != nullptr;
+
+    wf4 av[2][U][MT], bv[2][U][NT];
+    auto fetch = [&](int buf, int kg) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(kg + u, kq - 1);             // (kq is a multiple of U for every layer of the chain)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[buf][u][m] = wp[m][(long)k * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[buf][u][t] = xp[t][(long)k * 64];
+        }
+    };
+    auto compute = [&](int buf, int kg) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kg + u < kq) {
+                if (want_ln) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const wf4 x = bv[buf][u][t];
+                        s1[t] += (x[0] + x[1]) + (x[2] + x[3]);
+                        s2[t] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[m][t][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][u][m][j], bv[buf][u][t][j], acc[m][t][j & 1], 0, 0, 0);
+            }
+        }
+    };
+    // two register buffers, indexed by literals only (a run-time buffer index would put the fragments in scratch)
+    fetch(0, 0);
+    for (int kg = 0; kg < kq; kg += 2 * U) {
+        if (kg + U < kq) fetch(1, kg + U);
+        compute(0, kg);
+        if (kg + 2 * U < kq) fetch(0, kg + 2 * U);
+        if (kg + U < kq) compute(1, kg + U);
+    }
+    f32x4 fin[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fin[m][t] = acc[m][t][0] + acc[m][t][1];
+
+    if (KSPLIT == 4) {
+        // K quarters meet in LDS: waves 1..3 publish, wave 0 adds them in a fixed order and runs the epilogue
+        if (wave > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<f32x4*>(red + (((wave - 1) * MT + m) * NT + t) * 256 + lane * 4) = fin[m][t];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fin[m][t] += *reinterpret_cast<const f32x4*>(red + ((w * MT + m) * NT + t) * 256 + lane * 4);
+    }
+
+    // LayerNorm statistics of each lane's token: the four g4 lanes of a column hold the four channel residues
+    float mu[NT], rstd[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        mu[t] = 0.f;
+        rstd[t] = 1.f;
+        if (want_ln) {
+            float u = s1[t], v = s2[t];
+            u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+            u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+            const float mean = u / (float)a.K;
+            const float var = fmaxf(v / (float)a.K - mean * mean, 0.f);
+            mu[t] = mean;
+            rstd[t] = 1.0f / sqrtf(var + 1e-5f);
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int rt = rt0 + m;
+        if (rt >= ngm) continue;
+        const int row0 = rt * 16 + g4 * 4;                 // this lane's four output rows
+        float bb[4], ss[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bb[r] = a.bias[row0 + r];
+            ss[r] = want_ln ? a.lnsum[row0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tile = tt0 + t;
+            if (tile >= a.ntile) continue;
+            const int tok = tile * 16 + col;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = fin[m][t][r];
+                if (want_ln) y = rstd[t] * (y - mu[t] * ss[r]);
+                v[r] = act_apply(y + bb[r], a.act);
+            }
+            if (a.out_tok) {
+                if (tok < a.HW)
+                    *reinterpret_cast<float4*>(a.out_tok + b * a.out_bs + (long)tok * a.M + row0) = float4{v[0], v[1], v[2], v[3]};
+                continue;
+            }
+            if (a.mask_w > 0 && tok < a.HW) {
+                const int y = tok / a.mask_w, x = tok - y * a.mask_w;
+                const int rr = y + a.mask_pt, cc = x + a.mask_pl;
+                if ((rr < 7 && (rr & 1)) || (cc < 7 && (cc & 1))) v[0] = v[1] = v[2] = v[3] = 0.f;
+            }
+            // FRAG16 position of (token, row0 + r): group rt, lane (col + 16 r), element g4
+            const long fo = ((long)tile * ngm + rt) * 256 + col * 4 + g4;
+            if (a.res) {
+                const float* rp = a.res + b * a.res_bs + fo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rp[r * 64];
+            }
+            if (a.addres) {
+                const float* rp = a.addres + b * a.addres_bs + fo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rp[r * 64];
+            }
+            float* op = a.out_frag + b * a.out_bs + fo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) op[r * 64] = v[r];
+            if (a.out_nchw && tok < a.HW) {
+                float* np = a.out_nchw + b * a.nchw_bs + (long)row0 * a.HW + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) np[(long)r * a.HW] = v[r];
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int KSPLIT>
+static int tokgemm_launch_t(const TokGemmArgs& a, int B, hipStream_t s) {
+    const int ngm = a.M / 16;
+    dim3 grid(cdiv(a.ntile, NT), KSPLIT == 1 ? cdiv(ngm, 4 * MT) : cdiv(ngm, MT), B);
+    hipLaunchKernelGGL((tokgemm_kernel<MT, NT, KSPLIT>), grid, dim3(256), 0, s, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+// Decomposition of one GEMM of the chain: enough waves for the 1024 SIMDs, each with as long an MFMA chain as that allows.
+static int tokgemm_launch(const TokGemmArgs& a, int B, hipStream_t s) {
+    if (a.K % 64 != 0 || a.M % 16 != 0)
+        return fail(BDE_ERR_UNSUPPORTED, "token GEMM: K=%d must be a multiple of 64, M=%d of 16", a.K, a.M);
+    const long tiles = (long)a.ntile * (a.M / 16) * B;     // 16 x 16 output tiles
+    if (a.K >= 1024 && tiles < 4096) return tokgemm_launch_t<1, 1, 4>(a, B, s);
+    if (tiles >= 16384) return tokgemm_launch_t<2, 2, 1>(a, B, s);
+    if (tiles >= 4096) return tokgemm_launch_t<2, 2, 1>(a, B, s);
+    if (tiles >= 1536) return tokgemm_launch_t<1, 2, 1>(a, B, s);
+    return tokgemm_launch_t<1, 1, 1>(a, B, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnTokArgs {
+    const float* q;               // token-major [B][HW][q_ld]: the query frame's q | k | v rows
+    const float* kv[ATT_MAXD];    // per slot: token-major rows holding K at +k_off[d], V at +v_off[d]; nullptr = zero frame
+    long q_bs, kv_bs[ATT_MAXD];
+    int q_ld, kv_ld[ATT_MAXD], k_off[ATT_MAXD], v_off[ATT_MAXD];
+    const float* kvpad;           // [2C] K | V of a zero token
+    const float* biasT;           // [heads][D*49][49], query index fastest, log2(e) folded
+    float* out;                   // FRAG16 [B][ntile][C/16][256]
+    long out_bs;
+    int D, C, heads, H, W, Hp, Wp, pt, pl, nWw, dilated, ntile;
+};
+
+// softmax(q k^T + bias) v for one (window, head), head_dim 16; four waves = four tiles of 16 queries (attn_mfma.h).
+// The 16 channels of the head are contracted in the order (4 g4 + ks): a lane's 16-byte load of q is then its four
+// B-operand values as they stand, and K is staged into LDS rows in the same order.
+__global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
+    constexpr int HD = 16, NT = 10;
+    __shared__ __align__(16) float KL[NT * HD * 16];
+    __shared__ __align__(16) float VL[NT * 16 * HD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, col = lane & 15;
+    const int win = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int wi = win / a.nWw, wj = win - wi * a.nWw;
+    const int step = a.dilated ? 2 : 1;
+    const int c0 = head * HD;
+    const int nkey = a.D * ATT_TOK;
+    auto token_pixel = [&](int tok) {
+        const int ta = tok / ATT_WS, tb = tok - ta * ATT_WS;
+        const int rp = wi * ATT_WS + ta * step, cp = wj * ATT_WS + tb * step;
+        const int ry = rp - a.pt, rx = cp - a.pl;
+        return (rp < a.Hp && cp < a.Wp && ry >= 0 && ry < a.H && rx >= 0 && rx < a.W) ? ry * a.W + rx : -1;
+    };
+    const int qi = wave * 16 + col;
+    const int qpix = qi < ATT_TOK ? token_pixel(qi) : -1;
+    wf4 qv = *reinterpret_cast<const wf4*>(a.q + b * a.q_bs + (long)max(qpix, 0) * a.q_ld + c0 + 4 * g4);
+    if (qpix < 0) qv = wf4{0.f, 0.f, 0.f, 0.f};
+    const float* bias = a.biasT + (long)head * nkey * ATT_TOK + min(qi, ATT_TOK - 1);
+    f32x4 sc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = j * 16 + g4 * 4 + r;
+            const float bvv = bias[(long)min(u, nkey - 1) * ATT_TOK];
+            sc[j][r] = u < nkey ? bvv : -1e30f;
+        }
+    {
+        wf4 kk[3], vv[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int it = min(tid + t * 256, NT * 16 * 4 - 1);
+            const int u = it >> 2, cg = it & 3;
+            const int d = min(u / ATT_TOK, a.D - 1), tok = u - (u / ATT_TOK) * ATT_TOK;
+            const int pix = u < nkey ? token_pixel(tok) : -1;
+            const float* kp = u < nkey ? a.kv[d] : nullptr;
+            const bool use = pix >= 0 && kp != nullptr;
+            const float* ksrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.k_off[d] + c0 + cg * 4 : a.kvpad + c0 + cg * 4;
+            const float* vsrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.v_off[d] + c0 + cg * 4 : a.kvpad + a.C + c0 + cg * 4;
+            kk[t] = *reinterpret_cast<const wf4*>(ksrc);
+            vv[t] = *reinterpret_cast<const wf4*>(vsrc);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int it = tid + t * 256;
+            if (it < NT * 16 * 4) {
+                const int u = it >> 2, cg = it & 3;
+                // channel cg*4 + e of the head is contracted at k-step e by the lanes g4 = cg: LDS row e*4 + cg
+#pragma unroll
+                for (int e = 0; e < 4; ++e) KL[((u >> 4) * HD + e * 4 + cg) * 16 + (u & 15)] = kk[t][e];
+                *reinterpret_cast<wf4*>(VL + u * HD + cg * 4) = vv[t];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            sc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(KL[(j * HD + ks * 4 + g4) * 16 + col], qv[ks], sc[j], 0, 0, 0);
+    float mx = sc[0][0];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        mx = fmaxf(mx, fmaxf(sc[j][0], sc[j][1]));
+        mx = fmaxf(mx, fmaxf(sc[j][2], sc[j][3]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        float p[4], va[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(sc[j][r] - mx);
+            va[r] = VL[(j * 16 + g4 * 4 + r) * HD + col];
+            l += p[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r], p[r], acc, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qpix >= 0) {
+        const float inv = 1.f / l;
+        // rows of acc = channels c0 + 4 g4 + r of query pixel qpix: FRAG16 group `head`, lane (pixel column + 16 r), element g4
+        float* op = a.out + b * a.out_bs + ((long)(qpix >> 4) * (a.C >> 4) + head) * 256 + (qpix & 15) * 4 + g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[r * 64] = acc[r] * inv;
+    }
+}
+
+static int attn_tok16_launch(const AttnTokArgs& a, int B, hipStream_t s) {
+    const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
+    hipLaunchKernelGGL(attn_tok16_kernel, dim3(nW, a.heads, B), dim3(256), 0, s, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+}  // namespace bde

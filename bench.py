@@ -95,6 +95,8 @@ class Work:
         if m is None:
             return None
         base, idx = m.group(1), int(m.group(2)) if m.group(2) else None
+        if base.startswith('wide_'):                      # the fragment-layout chain runs the same GEMMs as the split path
+            base = 'chain_' + base[5:]
         if base == 'head':
             return 2.0 * c.basechannels * c.num_bins * c.ks ** 2 * self.H * self.W * TB, 'mfma'
         if base == 'enc_conv':
@@ -165,6 +167,8 @@ KERNEL_OF_SPAN = [
     (r'dec_conv(\d)', r'conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_vec.h)'),
     (r'head', r'conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_vec.h)'),
     (r'chain_(\w+?)(\d)', r'pw_gemm_kernel|attn_mfma16_kernel|attn_core_kernel|token_fused_kernel', 'split attention path of level {1}: {0}'),
+    (r'wide_core(\d)', r'attn_tok16_kernel', 'window-attention core of level {0}, one workgroup per (window, head) (csrc/wideblock.h)'),
+    (r'wide_(\w+?)(\d)', r'tokgemm_kernel', 'token GEMM of the level-{1} attention chain: {0} (csrc/wideblock.h)'),
 ]
 
 

@@ -18,7 +18,8 @@ import sys
 # bench.py span -> predicate on (kernel name, grid size): a span can share a kernel template with others; the grid tells them apart
 SPAN_KERNELS = [
     ('winblock0', r'winblock_kernel'),
-    ('wideblock2', r'wideblock_'),
+    ('wide_gemm', r'tokgemm_kernel'),
+    ('wide_core2', r'attn_tok16_kernel'),
     ('lstm0', r'lstm16_step_kernel<1, 128, 2'),
     ('lstm1', r'lstm16_step_kernel<1, 64, 1'),
     ('lstm2', r'lstm16_step_kernel<2, 32, 1'),
