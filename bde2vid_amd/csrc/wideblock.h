@@ -91,7 +91,10 @@ struct TokGemmArgs {
 // A wave computes MT row tiles x NT token tiles over 1/KSPLIT of K.  KSPLIT == 1: the four waves of a workgroup take
 // four consecutive groups of MT row tiles for the same tokens (the B fragments of three of them are L1 hits);
 // KSPLIT == 4: they take the four quarters of K of the same tiles and meet in LDS.
-template <int MT, int NT, int KSPLIT>
+// PRE > 0: the wave's whole operand stream (up to PRE channel groups, K <= 16 PRE per wave) is requested before the first
+// MFMA -- the launches on the sequential chain have one or two waves per SIMD, so what counts is that the L2 round trip
+// is paid once, not once per batch of fragments; PRE == 0 streams through two register buffers (the T-batched launches).
+template <int MT, int NT, int KSPLIT, int PRE>
 __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
     static_assert(KSPLIT == 1 || KSPLIT == 4, "");
     constexpr int U = 4;                                   // channel groups (of 16) fetched per batch
@@ -127,7 +130,61 @@ __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.f;
     const bool want_ln = a.lnsum != nullptr;
+    // epilogue operands go out with the operand stream (a load issued after the MFMA loop is a round trip on the
+    // critical path of a launch that lives for a few microseconds)
+    float bb[MT][4], ss[MT][4], rs[MT][NT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row0 = min(rt0 + m, ngm - 1) * 16 + g4 * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bb[m][r] = a.bias[row0 + r];
+            ss[m][r] = want_ln ? a.lnsum[row0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const long fo = ((long)min(tt0 + t, a.ntile - 1) * ngm + min(rt0 + m, ngm - 1)) * 256 + col * 4 + g4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.f;
+                if (a.res) v = a.res[b * a.res_bs + fo + r * 64];
+                if (a.addres) v += a.addres[b * a.addres_bs + fo + r * 64];
+                rs[m][t][r] = v;
+            }
+        }
+    }
 
+    if constexpr (PRE > 0) {
+        wf4 av[PRE][MT], bv[PRE][NT];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const int kk = min(k, kq - 1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[k][m] = wp[m][(long)kk * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[k][t] = xp[t][(long)kk * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            if (k < kq) {
+                if (want_ln) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const wf4 x = bv[k][t];
+                        s1[t] += (x[0] + x[1]) + (x[2] + x[3]);
+                        s2[t] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[m][t][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][m][j], bv[k][t][j], acc[m][t][j & 1], 0, 0, 0);
+            }
+        }
+    } else {
     wf4 av[2][U][MT], bv[2][U][NT];
     auto fetch = [&](int buf, int kg) {
 #pragma unroll
@@ -168,6 +225,7 @@ __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
         compute(0, kg);
         if (kg + 2 * U < kq) fetch(0, kg + 2 * U);
         if (kg + U < kq) compute(1, kg + U);
+    }
     }
     f32x4 fin[MT][NT];
 #pragma unroll
@@ -216,12 +274,6 @@ __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
         const int rt = rt0 + m;
         if (rt >= ngm) continue;
         const int row0 = rt * 16 + g4 * 4;                 // this lane's four output rows
-        float bb[4], ss[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bb[r] = a.bias[row0 + r];
-            ss[r] = want_ln ? a.lnsum[row0 + r] : 0.f;
-        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int tile = tt0 + t;
@@ -231,8 +283,8 @@ __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float y = fin[m][t][r];
-                if (want_ln) y = rstd[t] * (y - mu[t] * ss[r]);
-                v[r] = act_apply(y + bb[r], a.act);
+                if (want_ln) y = rstd[t] * (y - mu[t] * ss[m][r]);
+                v[r] = act_apply(y + bb[m][r], a.act);
             }
             if (a.out_tok) {
                 if (tok < a.HW)
@@ -246,16 +298,8 @@ __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
             }
             // FRAG16 position of (token, row0 + r): group rt, lane (col + 16 r), element g4
             const long fo = ((long)tile * ngm + rt) * 256 + col * 4 + g4;
-            if (a.res) {
-                const float* rp = a.res + b * a.res_bs + fo;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rp[r * 64];
-            }
-            if (a.addres) {
-                const float* rp = a.addres + b * a.addres_bs + fo;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rp[r * 64];
-            }
+            for (int r = 0; r < 4; ++r) v[r] += rs[m][t][r];
             float* op = a.out_frag + b * a.out_bs + fo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) op[r * 64] = v[r];
@@ -268,25 +312,29 @@ __global__ __launch_bounds__(256) void tokgemm_kernel(const TokGemmArgs a) {
     }
 }
 
-template <int MT, int NT, int KSPLIT>
+template <int MT, int NT, int KSPLIT, int PRE>
 static int tokgemm_launch_t(const TokGemmArgs& a, int B, hipStream_t s) {
     const int ngm = a.M / 16;
     dim3 grid(cdiv(a.ntile, NT), KSPLIT == 1 ? cdiv(ngm, 4 * MT) : cdiv(ngm, MT), B);
-    hipLaunchKernelGGL((tokgemm_kernel<MT, NT, KSPLIT>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((tokgemm_kernel<MT, NT, KSPLIT, PRE>), grid, dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 
+inline bool wide_nt2() { return tuning().pw_force == 121; }   // (experiment switch: two token tiles per wave)
 // Decomposition of one GEMM of the chain: enough waves for the 1024 SIMDs, each with as long an MFMA chain as that allows.
 static int tokgemm_launch(const TokGemmArgs& a, int B, hipStream_t s) {
     if (a.K % 64 != 0 || a.M % 16 != 0)
         return fail(BDE_ERR_UNSUPPORTED, "token GEMM: K=%d must be a multiple of 64, M=%d of 16", a.K, a.M);
     const long tiles = (long)a.ntile * (a.M / 16) * B;     // 16 x 16 output tiles
-    if (a.K >= 1024 && tiles < 4096) return tokgemm_launch_t<1, 1, 4>(a, B, s);
-    if (tiles >= 16384) return tokgemm_launch_t<2, 2, 1>(a, B, s);
-    if (tiles >= 4096) return tokgemm_launch_t<2, 2, 1>(a, B, s);
-    if (tiles >= 1536) return tokgemm_launch_t<1, 2, 1>(a, B, s);
-    return tokgemm_launch_t<1, 1, 1>(a, B, s);
+    const int ngk = a.K / 16;
+    if (a.K >= 1024 && tiles < 4096) {                     // few tiles, long K: the four waves of a workgroup split K
+        if (ngk / 4 <= 16) return tokgemm_launch_t<1, 1, 4, 16>(a, B, s);
+        return tokgemm_launch_t<1, 1, 4, 0>(a, B, s);
+    }
+    if (tiles >= 4096) return tokgemm_launch_t<2, 2, 1, 0>(a, B, s);
+    if (tiles >= 1536 && wide_nt2()) return ngk <= 16 ? tokgemm_launch_t<1, 2, 1, 16>(a, B, s) : tokgemm_launch_t<1, 2, 1, 0>(a, B, s);
+    return ngk <= 16 ? tokgemm_launch_t<1, 1, 1, 16>(a, B, s) : tokgemm_launch_t<1, 1, 1, 0>(a, B, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
