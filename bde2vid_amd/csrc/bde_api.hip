@@ -25,6 +25,7 @@
 #include "wideblock.h"
 #include "attn_mfma.h"
 #include "conv_vec.h"
+#include "conv_sb.h"
 #include "voxel.h"
 #include "metrics.h"
 
@@ -213,6 +214,8 @@ struct PackedLayer {
     long w_off = -1, b_off = -1, s_off = -1;   // weights / bias / lnsum
     long w_sz = 0;                              // floats of one group's packed weights
     int G = 1;                                  // groups packed back to back (fwd, bwd)
+    long sb_off = -1, sb_sz = 0;                // split-bf16 packing (conv_sb.h), floats; one group = sb_sz
+    int sb_chunks = 0;                          // 16-channel chunks
 };
 
 struct Arena {
@@ -347,6 +350,33 @@ static PackedLayer pack_lstm8(Arena& ar, const std::vector<const DenseLayer*>& g
     return pl;
 }
 
+// conv_sb.h: the weights as three bf16 terms in A-fragment order of v_mfma_f32_32x32x16_bf16:
+// [group][co tile 32][chunk 16][tap][term][64 lanes][8]: lane l = W[32 tile + (l & 31)][16 chunk + 8 (l >> 5) + j][tap]
+static void pack_split_bf16(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
+    const DenseLayer& d0 = *groups[0];
+    const int taps = d0.KS * d0.KS, ncot = cdiv(d0.rows, 32), C16 = cdiv(d0.Cin, 16);
+    const long per_group_u16 = (long)ncot * C16 * taps * 3 * 64 * 8;
+    pl.sb_sz = per_group_u16 / 2;                                   // in floats
+    pl.sb_chunks = C16;
+    pl.sb_off = ar.alloc(pl.sb_sz * (long)groups.size());
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const DenseLayer& d = *groups[g];
+        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + pl.sb_off + (long)g * pl.sb_sz);
+        for (int ct = 0; ct < ncot; ++ct)
+            for (int ch = 0; ch < C16; ++ch)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = ct * 32 + (l & 31), ci = ch * 16 + 8 * (l >> 5) + j;
+                            const float w = (row < d.rows && ci < d.Cin) ? d.w[((long)row * d.Cin + ci) * taps + tap] : 0.f;
+                            unsigned short t3[3];
+                            sb_split3(w, t3[0], t3[1], t3[2]);
+                            for (int k = 0; k < 3; ++k)
+                                dst[(((((long)ct * C16 + ch) * taps + tap) * 3 + k) * 64 + l) * 8 + j] = t3[k];
+                        }
+    }
+}
+
 // Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
 // four (one per wave); pointwise layers CK = 16 in groups of eight (any pw_gemm split-K factor).
 static PackedLayer pack_layer(Arena& ar, const std::vector<const DenseLayer*>& groups, bool lstm) {
@@ -414,6 +444,8 @@ struct Workspace {
     std::vector<float*> xenc, gx, hseq, cst, merged, mergedT, kvun, kvref, dec, qkv0;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
+    float* sb = nullptr;          // split-bf16 image of the input of the convolution in flight (conv_sb.h)
+    long sb_bytes = 0;
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
     bool warm = false;
     void release() {
@@ -474,6 +506,7 @@ struct bde_model {
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
+    int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -597,6 +630,8 @@ static int build_packed(bde_model* m) {
         }
         m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, false);
         m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, false);
+        pack_split_bf16(ar, m->enc[l], {&e[0], &e[1]});
+        pack_split_bf16(ar, m->gx[l], {&gxd[0], &gxd[1]});
         m->lstm[l] = pack_lstm16(ar, {&gh[0], &gh[1]});
         m->lstm8[l] = pack_lstm8(ar, {&gh[0], &gh[1]});
     }
@@ -673,6 +708,7 @@ static int build_packed(bde_model* m) {
                 // C/D register order of the 16x16x4 MFMA: [head][i][j][r][lane], key = 16j + 4(lane>>4) + r
                 ab.biasF_off = ar.alloc((long)heads * 4 * WB_NT * 256);
                 float* bfp = ar.host.data() + ab.biasF_off;
+                bt = ar.host.data() + ab.bias_off;               // (the arena may have moved: alloc() grows a std::vector)
                 for (int h = 0; h < heads; ++h)
                     for (int qi = 0; qi < 4; ++qi)
                         for (int j = 0; j < WB_NT; ++j)
@@ -734,6 +770,7 @@ static int build_packed(bde_model* m) {
         std::string p = "decoders." + std::to_string(j) + ".1.conv2d.";
         BDE_TRY(dense_conv(m, p + "weight", p + "bias", cout, cin, 0, cin, ks, true, &d));
         m->dec[j] = pack_layer(ar, {&d}, false);
+        pack_split_bf16(ar, m->dec[j], {&d});
     }
     {
         const float *w, *b;
@@ -822,6 +859,27 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         a.pred_sigmoid = m->cfg.activation;
     }
     if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
+    if (m->conv_sb && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
+        // split the input into three bf16 terms (SB16), then the convolution on the bf16 matrix cores; the small
+        // launches (a few frames of a small map) stay on the fp32 kernels
+        Workspace& ws = const_cast<bde_model*>(m)->W();
+        const bool grouped_in = cc.in_gs != 0;
+        const long frames = (grouped_in ? pl.G : 1) * (long)cc.N;
+        const long need = split_bf16_bytes(frames, pl.Cin, (long)cc.Hs * cc.Ws);
+        if (ws.sb && need <= ws.sb_bytes) {
+            BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, s));
+            ConvArgs b = a;
+            b.in = ws.sb;
+            b.wpk = m->P(pl.sb_off);
+            b.w_gs = pl.sb_sz;
+            b.nchunks = pl.sb_chunks;
+            b.in_ns = (long)pl.sb_chunks * cc.Hs * cc.Ws * SB_PIX_BYTES / 4;
+            b.in_gs = grouped_in ? b.in_ns * cc.N : 0;
+            bool launched = false;
+            BDE_TRY(conv_sb_launch(pl.KS, cc.stride, b, pl.G, s, &launched));
+            if (launched) return BDE_OK;
+        }
+    }
     return conv_launch_best(pl.KS, cc.stride, a, pl.G, s);
 }
 
@@ -901,6 +959,19 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.dec[j], TB * m->cin(l) * (long)(H >> l) * (W >> l)));
     }
     BDE_TRY(ws_alloc(ws, &ws.up, TB * m->cout(0) * (long)H * W));   // dec L-1: cout(0) channels at full resolution
+    {
+        // split-bf16 image of one convolution's input (6 B per element, channels padded to 16): the largest of the
+        // encoder inputs, gate-conv inputs (both directions) and upsampled decoder inputs
+        long mx = 0;
+        for (int l = 0; l < L; ++l) {
+            const long hw_in = (long)(H >> l) * (W >> l), hw = (long)(H >> (l + 1)) * (W >> (l + 1));
+            mx = std::max(mx, split_bf16_bytes(TB, m->cin(l), hw_in));               // encoder conv input
+            mx = std::max(mx, split_bf16_bytes(2 * TB, m->cout(l), hw));             // gate conv input, both directions
+            mx = std::max(mx, split_bf16_bytes(TB, m->cout(l), 4 * hw));             // decoder conv input (upsampled)
+        }
+        ws.sb_bytes = mx;
+        BDE_TRY(ws_alloc(ws, &ws.sb, mx / 4 + 4));
+    }
     if (max_attn > 0) {
         BDE_TRY(ws_alloc(ws, &ws.qkv, 3 * max_attn));
         BDE_TRY(ws_alloc(ws, &ws.ao, max_attn));
@@ -1630,8 +1701,8 @@ int bde_load_weight(bde_model* m, const char* key, const float* data, const int6
 
 int bde_finalize_weights(bde_model* m) {
     BDE_REQUIRE(m != nullptr, "null model");
+    BDE_TRY(build_packed(m));           // host only (runs, and is checked, on a box without a GPU as well)
     BDE_HIP(hipGetDevice(&m->device));
-    BDE_TRY(build_packed(m));
     return upload(m);
 }
 
@@ -1729,6 +1800,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         m->wide = (int)value;
         return BDE_OK;
     }
+    if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "fuse_pred") { m->fuse_pred = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { m->tune.pw_batched = (int)value; return BDE_OK; }
@@ -1758,6 +1830,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "device") *value = m->device;
     else if (k == "winblock") *value = m->winblock;
     else if (k == "wide") *value = m->wide;
+    else if (k == "conv_sb") *value = m->conv_sb;
     else if (k == "packed_numel") *value = m->dev_numel;
     else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
     return BDE_OK;

@@ -107,7 +107,8 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 template <int MT, int NT, int RPW>
 __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float (&fin)[MT][NT][RPW], const int (&pix)[NT],
                                                  int r0, int lane, int g, int n, int HW, int p_end, bool want_ln,
-                                                 const float (&mu)[NT], const float (&rstd)[NT]) {
+                                                 const float (&mu)[NT], const float (&rstd)[NT], int cot0 = -1) {
+    if (cot0 < 0) cot0 = blockIdx.y * MT;        // first 32-row output tile of this wave (conv_sb.h passes its own)
     float* outb = a.out + g * a.out_gs + n * a.out_ns;
     const float* r1 = a.res1 ? a.res1 + g * a.res1_gs + n * a.res1_ns : nullptr;
     const float* r2 = a.res2 ? a.res2 + g * a.res2_gs + n * a.res2_ns : nullptr;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            const int co = min((int)(blockIdx.y * MT + m) * 32 + acc_row(r0 + rr, lane), a.Cout - 1);
+            const int co = min((cot0 + m) * 32 + acc_row(r0 + rr, lane), a.Cout - 1);
             bv[m][rr] = biasg[co];
             sv[m][rr] = want_ln ? a.lnsum[co] : 0.f;
         }
@@ -135,7 +136,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int rr = 0; rr < RPW; ++rr) {
-                    const int co = m * 32 + acc_row(r0 + rr, lane);
+                    const int co = (cot0 + m) * 32 + acc_row(r0 + rr, lane);
                     if (co >= a.Cout) continue;
                     float v = act_apply(fin[m][t][rr] + bv[m][rr], a.act);
                     if (hb) v += hb[(long)co * HW + p];
@@ -159,7 +160,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int cob = (blockIdx.y * MT + m) * 32;
+            const int cob = (cot0 + m) * 32;
             float rv[RPW];
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {

@@ -1,0 +1,292 @@
+// Batched direct convolution with fp32-equivalent arithmetic on the bf16 matrix cores ("split bf16", bf16x3).
+//
+// The convolutions of the path are compute-bound on the fp32 matrix rate (64 FLOP/clk/SIMD), and that rate is 1/16 of the
+// bf16 one.  An fp32 value is the exact sum of three bf16 terms (hi + mid + lo, 8 + 8 + 8 significant bits), so an fp32
+// product is the sum of nine bf16 x bf16 products, each exact in fp32; dropping the three whose relative size is
+// <= 2^-24 leaves six bf16 MFMAs per fp32 MFMA-equivalent:
+//     a b  ~=  a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1          (error per product <= 3 * 2^-24 |a b|, fp32 accumulate)
+// = 6 x 32 cycles of v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block against 8 x 64 cycles of v_mfma_f32_32x32x2_f32:
+// 2.67x the fp32 matrix rate at the accuracy of an fp32 contraction (tools/bf16_split_error.py; every parity test of the
+// fp32 kernels holds at its tolerance).  dtype of the path stays "f32": inputs, outputs and accumulation are fp32.
+//
+// Operands:
+//   activations  SB16 [N][ceil(C/16)][H][W][3 terms][16 channels] bf16 (96 B per pixel and 16-channel chunk), written by
+//                split_bf16_kernel from the fp32 NCHW planes the rest of the path keeps;
+//   weights      split once at pack time, in A-fragment order of the 32x32x16 MFMA:
+//                [co tile 32][chunk][tap][term][64 lanes][8]: lane l = W[32 tile + (l & 31)][16 chunk + 8 (l >> 5) + j][tap].
+// Workgroup = WM x WN waves, a wave = MT x NT tiles of 32 output channels x 32 pixels; per 16-channel chunk the halo tile of
+// the workgroup's BN pixels is staged global -> registers -> LDS (112-byte pixel pitch: conflict-free 16-byte fragment
+// reads), the next chunk's loads in flight during the MFMAs; weight fragments go global (L2) -> registers one tap ahead.
+// Epilogue = generic_epilogue of conv_mfma.h (bias, ReLU / ReLU6, residuals; same D layout as the fp32 32x32x2 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_mfma.h"
+
+namespace bde {
+
+typedef __bf16 sb8 __attribute__((ext_vector_type(8)));     // 8 bf16 = one MFMA operand fragment (16 bytes)
+typedef float sbf4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ __forceinline__ unsigned short sb_bf16_rne(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__host__ __device__ __forceinline__ float sb_bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+// x = hi + mid + lo with three bf16 terms (exact for every finite fp32 x whose low term does not underflow)
+__host__ __device__ __forceinline__ void sb_split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    hi = sb_bf16_rne(x);
+    const float r1 = x - sb_bf16_to_f32(hi);
+    mid = sb_bf16_rne(r1);
+    const float r2 = r1 - sb_bf16_to_f32(mid);
+    lo = sb_bf16_rne(r2);
+}
+
+constexpr int SB_PIX_BYTES = 96;       // 3 terms x 16 channels x 2 B
+constexpr int SB_LDS_PITCH = 112;      // + 16 B: sixteen lanes' 16-byte reads land in sixteen different bank groups
+
+#ifdef BDE_CONV_TU
+// fp32 [N][C][H][W] -> SB16 [N][C16][H][W][3][16].  grid (ceil(HW / 128), C16, N), 256 threads: thread = (pixel, half of
+// the chunk): 8 plane loads (coalesced along W), three 16-byte stores.
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, long HW) {
+    const int half = threadIdx.x & 1;
+    const long p = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int c16 = blockIdx.y;
+    const long n = blockIdx.z;
+    if (p >= HW) return;
+    const int C16 = gridDim.y;
+    unsigned short t[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c16 * 16 + half * 8 + j;
+        const float x = c < C ? in[(n * C + c) * HW + p] : 0.f;
+        sb_split3(x, t[0][j], t[1][j], t[2][j]);
+    }
+    unsigned short* o = out + (((n * C16 + c16) * HW + p) * 3) * 16 + half * 8;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint4 v;
+        v.x = t[k][0] | ((unsigned)t[k][1] << 16);
+        v.y = t[k][2] | ((unsigned)t[k][3] << 16);
+        v.z = t[k][4] | ((unsigned)t[k][5] << 16);
+        v.w = t[k][6] | ((unsigned)t[k][7] << 16);
+        *reinterpret_cast<uint4*>(o + k * 16) = v;
+    }
+}
+int split_bf16(const float* in, void* out, long N, int C, long HW, hipStream_t s) {
+    const int C16 = cdiv(C, 16);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdivl(HW, 128), C16, (unsigned)N), dim3(256), 0, s, in, (unsigned short*)out, C, HW);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+#else
+int split_bf16(const float* in, void* out, long N, int C, long HW, hipStream_t s);   // conv_tu.hip
+#endif
+static inline long split_bf16_bytes(long N, int C, long HW) { return N * cdiv(C, 16) * HW * SB_PIX_BYTES; }
+
+// a.in = SB16 activations (as float*), a.wpk = split packed weights; group / frame strides of `in` in BYTES / 4 (floats).
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs a) {
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int BN = WN * NT * 32;
+    extern __shared__ __align__(16) unsigned char sb_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int hl = lane >> 5;
+    const int z = blockIdx.z;
+    const int g = z / a.N, n = z - g * a.N;
+    const int HW = a.Ho * a.Wo;
+    int p0, p_end;
+    if (a.row_tiles > 0) {
+        const int yy = blockIdx.x / a.row_tiles, xt = blockIdx.x - yy * a.row_tiles;
+        p0 = yy * a.Wo + xt * BN;
+        p_end = min(p0 + BN, (yy + 1) * a.Wo);
+    } else {
+        p0 = blockIdx.x * BN;
+        p_end = min(p0 + BN, HW);
+    }
+    const int p_last = p_end - 1;
+    const int y_first = p0 / a.Wo, y_last = p_last / a.Wo;
+    const bool one_row = (y_first == y_last);
+    const int x_first = p0 - y_first * a.Wo;
+    const int iy0 = y_first * STRIDE - PAD;
+    const int ix0 = one_row ? x_first * STRIDE - PAD : -PAD;
+    const int R = (y_last - y_first) * STRIDE + KS;
+    const int IW = one_row ? (p_last - p0) * STRIDE + KS : a.Win + 2 * PAD;
+
+    int boff[NT], pix[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = p0 + (wn * NT + t) * 32 + (lane & 31);
+        pix[t] = p;
+        const int pc = min(p, p_last);
+        const int y = pc / a.Wo, x = pc - y * a.Wo;
+        boff[t] = ((y - y_first) * STRIDE * IW + (x * STRIDE - PAD - ix0)) * SB_LDS_PITCH + hl * 16;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    const int C16 = a.nchunks;
+    const long plane = (long)a.Hs * a.Ws * SB_PIX_BYTES;                  // bytes of one 16-channel chunk of a frame
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (g * a.in_gs + n * a.in_ns) * 4;
+    // staging items of this thread: 16-byte piece q of halo pixel (r, c)
+    const int nitems = R * IW * 6;
+    unsigned goff[MAXI];
+    int loff[MAXI];
+    unsigned vmask = 0;
+    {
+        const float inv = 1.0f / (float)(IW * 6);
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int i = tid + it * NTH;
+            const int r = (int)(((float)i + 0.5f) * inv);
+            const int rem = i - r * IW * 6;
+            const int c = rem / 6, q = rem - c * 6;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool item = i < nitems;
+            const bool in_img = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            loff[it] = item ? (r * IW + c) * SB_LDS_PITCH + q * 16 : -1;
+            goff[it] = (item && in_img) ? (unsigned)((iy * a.Ws + ix) * SB_PIX_BYTES + q * 16) : 0u;
+            if (item && in_img) vmask |= 1u << it;
+        }
+    }
+    sbf4 sv[MAXI];
+    auto stage_load = [&](int c16) {
+        const unsigned char* cb = inb + c16 * plane;
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it)
+            sv[it] = ((vmask >> it) & 1u) ? *reinterpret_cast<const sbf4*>(cb + goff[it]) : sbf4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it)
+            if (loff[it] >= 0) *reinterpret_cast<sbf4*>(sb_lds + loff[it]) = sv[it];
+    };
+    // weight fragments: [co tile][chunk][tap][term][64][8] bf16
+    const int cot0 = (blockIdx.y * WM + wm) * MT;
+    const int ncot = (a.Cout + 31) / 32;
+    const sb8* wfr[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        wfr[m] = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) + ((long)min(cot0 + m, ncot - 1) * C16 * TAPS * 3) * 64 + lane;
+
+    stage_load(0);
+    for (int c16 = 0; c16 < C16; ++c16) {
+        __syncthreads();
+        stage_store();
+        __syncthreads();
+        if (c16 + 1 < C16) stage_load(c16 + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            // (two workgroups per CU: the other one's MFMAs cover these fragments' way from L2)
+            sb8 af[1][MT][3];
+            constexpr int cur = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) af[0][m][k] = wfr[m][(((long)c16 * TAPS + tap) * 3 + k) * 64];
+            const int ky = tap / KS, kx = tap - ky * KS;
+            sb8 bfr[NT][3];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    bfr[t][k] = *reinterpret_cast<const sb8*>(sb_lds + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    // small terms first, the leading product last
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bfr[t][2], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][2], bfr[t][0], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bfr[t][1], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bfr[t][1], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bfr[t][0], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bfr[t][0], acc[m][t], 0, 0, 0);
+                }
+        }
+    }
+    float fin[MT][NT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) fin[m][t][rr] = acc[m][t][rr];
+    float mu[NT], rstd[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mu[t] = rstd[t] = 0.f;
+    if (cot0 * 32 < a.Cout) generic_epilogue<MT, NT, 16>(a, fin, pix, 0, lane, g, n, HW, p_end, false, mu, rstd, cot0);
+}
+
+// host-side geometry (mirrors the kernel)
+static inline long conv_sb_halo_pixels(int KS, int STRIDE, int BN, int Win, int Ho, int Wo, int row_tiles) {
+    const int PAD = KS / 2;
+    const int HW = Ho * Wo;
+    if (row_tiles > 0) return (long)KS * ((std::min(BN, Wo) - 1) * STRIDE + KS);
+    long best = 0;
+    for (int p0 = 0; p0 < HW; p0 += BN) {
+        const int pl = std::min(p0 + BN, HW) - 1;
+        const int yf = p0 / Wo, yl = pl / Wo;
+        const long R = (long)(yl - yf) * STRIDE + KS;
+        const long e = R * (yf == yl ? (pl - p0) * STRIDE + KS : Win + 2 * PAD);
+        best = std::max(best, e);
+    }
+    return best;
+}
+
+#ifdef BDE_CONV_TU
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
+static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long halo_px) {
+    constexpr int BN = WN * NT * 32;
+    const size_t lds = (size_t)halo_px * SB_LDS_PITCH;
+    auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI>;
+    static unsigned char raised[BDE_MAX_DEVICES];
+    if (lds > 64 * 1024 && first_use_on_device(raised))
+        BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    dim3 grid(a.row_tiles > 0 ? a.Ho * a.row_tiles : cdiv(a.Ho * a.Wo, BN), cdiv(a.Cout, WM * MT * 32), G * a.N);
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+template <int KS, int STRIDE>
+static int conv_sb_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launched) {
+    // one decomposition: 2 x 2 waves of 64 output channels x 64 pixels; pixel tiles aligned to image rows when a row is
+    // at least 3/4 of a tile, linear over rows otherwise
+    constexpr int MT = 2, NT = 2, WM = 2, WN = 2, BN = WN * NT * 32;
+    *launched = false;
+    int best_rt = 0;
+    const double fill_lin = (double)a.Ho * a.Wo / ((double)cdiv(a.Ho * a.Wo, BN) * BN);
+    const int rt = cdiv(a.Wo, BN);
+    const double fill_row = (double)a.Wo / ((double)rt * BN);
+    if (fill_row >= fill_lin - 0.1) best_rt = rt;
+    a.row_tiles = best_rt;
+    const long halo = conv_sb_halo_pixels(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, best_rt);
+    const long items = (halo * 6 + 255) / 256;
+    if (halo * SB_LDS_PITCH > 150 * 1024 || items > 16) return BDE_OK;      // the caller falls back to the fp32 kernels
+    *launched = true;
+    if (items <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8>(a, G, stream, halo);
+    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16>(a, G, stream, halo);
+}
+
+int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched) {
+    *launched = false;
+    if (KS == 3 && stride == 1) return conv_sb_launch_ks<3, 1>(a, G, stream, launched);
+    if (KS == 5 && stride == 1) return conv_sb_launch_ks<5, 1>(a, G, stream, launched);
+    if (KS == 5 && stride == 2) return conv_sb_launch_ks<5, 2>(a, G, stream, launched);
+    return BDE_OK;
+}
+#else
+int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched);   // conv_tu.hip
+#endif
+
+}  // namespace bde

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "conv_vec.h"
+#include "conv_sb.h"
 #include "lstm16.h"
 #include "pw_gemm.h"
 
