@@ -859,7 +859,9 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         a.pred_sigmoid = m->cfg.activation;
     }
     if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
-    if (m->conv_sb && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
+    // (measured at the canonical sizes: 3x3 gate convs 728 / 632 us against 954 / 989 us on the fp32 matrix path, 5x5
+    //  convs 708 against 638 us: the 5x5 ones stay on the fp32 kernels unless conv_sb == 2)
+    if (m->conv_sb && (pl.KS == 3 || m->conv_sb >= 2) && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
         // split the input into three bf16 terms (SB16), then the convolution on the bf16 matrix cores; the small
         // launches (a few frames of a small map) stay on the fp32 kernels
         Workspace& ws = const_cast<bde_model*>(m)->W();
