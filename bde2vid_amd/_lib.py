@@ -58,6 +58,7 @@ SIGNATURES = {
     'bde_op_head': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'bde_op_recurrent_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     'bde_op_encoder_conv': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
+    'bde_op_gate_conv': (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     'bde_op_decoder': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
     'bde_op_pred': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'bde_op_dframe_attention': (_I, [_P, _I, _PP, _I, _I, _I, _I, _I, _P, _P]),

@@ -2025,6 +2025,7 @@ int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* i
     pl.G = 1;
     pl.w_off += dir * pl.w_sz;
     pl.b_off += (long)dir * pl.Cout;
+    if (pl.sb_off >= 0) pl.sb_off += dir * pl.sb_sz;
     ConvCall c;
     c.pl = &pl; c.in = in; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.stride = 2; c.act = ACT_RELU;
     return run_conv(m, c, (hipStream_t)stream);
@@ -2048,6 +2049,25 @@ int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float*
         BDE_HIP(hipMemcpyAsync(c_out, m->W().cst[level] + (long)dir * B * C * hw, sizeof(float) * B * C * hw,
                                hipMemcpyDeviceToDevice, s));
     return BDE_OK;
+}
+
+int bde_op_gate_conv(bde_model* m, int32_t level, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
+    // x-part of the ConvLSTM gates (submodules.py:316-317, the x half of the stacked input) for both directions:
+    // in [2][N][C][H][W] (forward / backward encoder outputs), out [2][N][4C][H][W], bias included
+    BDE_REQUIRE(m && m->finalized && in && out && level >= 0 && level < m->L && N >= 1, "bad argument");
+    TuningScope ts(&m->tune);
+    BDE_TRY(ensure_workspace(m, N, 1, H << (level + 1), W << (level + 1)));
+    const int C = m->cout(level);
+    ConvCall gxc;
+    gxc.pl = &m->gx[level];
+    gxc.in = in;
+    gxc.out = out;
+    gxc.N = N;
+    gxc.Hs = H;
+    gxc.Ws = W;
+    gxc.in_gs = (long)N * C * H * W;
+    gxc.out_gs = (long)N * 4 * C * H * W;
+    return run_conv(m, gxc, (hipStream_t)stream);
 }
 
 int bde_op_decoder(bde_model* m, int32_t j, const float* in, const float* skip, int32_t N, int32_t H, int32_t W,

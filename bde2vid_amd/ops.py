@@ -51,6 +51,15 @@ def recurrent_conv(m: BDE2VID, level, direction, x):
     return h, c
 
 
+def gate_conv(m: BDE2VID, level, x):
+    """x: [2, N, C, H, W] (forward / backward encoder outputs) -> [2, N, 4C, H, W]: W_x * x + bias of the gates."""
+    _chk(x)
+    _, N, Cc, H, W = x.shape
+    out = torch.empty((2, N, 4 * Cc, H, W), device=x.device)
+    _lib.check(_lib.lib().bde_op_gate_conv(m._h, level, C.c_void_p(x.data_ptr()), N, H, W, C.c_void_p(out.data_ptr()), _sp(m)))
+    return out
+
+
 def decoder(m: BDE2VID, j, x, skip: Optional[torch.Tensor] = None):
     _chk(x)
     N, _, H, W = x.shape

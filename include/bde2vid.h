@@ -187,6 +187,10 @@ int bde_op_recurrent_conv(bde_model* m, int32_t level, int32_t dir, const float*
                           int32_t H, int32_t W, float* h_out, float* c_out, void* stream);
 int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t N, int32_t H,
                         int32_t W, float* out, void* stream);
+/* x-part of the ConvLSTM gates of `level` for both directions (submodules.py:316-317 on the x half of the stacked input):
+ * in [2][N][C][H][W], out [2][N][4C][H][W], bias included. */
+int bde_op_gate_conv(bde_model* m, int32_t level, const float* in, int32_t N, int32_t H, int32_t W, float* out,
+                     void* stream);
 /* decoder j: out = ReLU6(conv(bilinear_x2(in + skip)))); skip may be NULL */
 int bde_op_decoder(bde_model* m, int32_t j, const float* in, const float* skip, int32_t N, int32_t H, int32_t W,
                    float* out, void* stream);

@@ -1,0 +1,68 @@
+"""Split-bf16 convolutions (csrc/conv_sb.h): fp32-equivalent arithmetic on the bf16 matrix cores.
+
+Every parity test of the fp32 kernels also runs through them (they are on by default for the 3x3 gate convolutions); here
+their error is measured against a float64 CPU reference next to the fp32 matrix-core kernel's own, i.e. the error table of
+tools/bf16_split_error.py reproduced on the GPU: six-term split products must stay within 2x of the fp32 kernel's error
+(plain bf16 would be ~1e-3 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import dense_like, maxabs
+from bde2vid_amd import canonical
+from bde2vid_amd.weights import formula_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def model_a():
+    from bde2vid_amd.model import build_model
+    cfg = canonical()
+    sd = formula_state_dict(cfg)
+    return cfg, sd, build_model(cfg, sd, 'cuda:0')
+
+
+@pytest.mark.parametrize('level,hw,N', [(0, (92, 120), 4), (1, (46, 60), 8), (2, (23, 30), 16), (0, (33, 47), 6)])
+def test_gate_conv_error_against_float64(model_a, level, hw, N):
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    C = cfg.enc_out(level)
+    x = torch.from_numpy(dense_like((2, N, C, hw[0], hw[1]), 900 + level))
+    ref = []
+    for d, name in enumerate(('forward_encoder', 'backward_encoder')):
+        w = sd[f'{O.P}{name}.{level}.recurrent_block.Gates.weight'][:, :C].double()      # x half of [x | h] (submodules.py:316)
+        b = sd[f'{O.P}{name}.{level}.recurrent_block.Gates.bias'].double()
+        ref.append(F.conv2d(x[d].double(), w, b, padding=1))
+    ref = torch.stack(ref)
+    scale = float(ref.abs().max())
+    xd = x.cuda()
+    m.set_tuning('conv_sb', 0)
+    y32 = ops.gate_conv(m, level, xd).cpu().double()
+    m.set_tuning('conv_sb', 1)
+    ysb = ops.gate_conv(m, level, xd).cpu().double()
+    e32 = float((y32 - ref).abs().max()) / scale
+    esb = float((ysb - ref).abs().max()) / scale
+    print(f'level {level} {hw}: fp32 matrix cores {e32:.2e}, split bf16 (6 terms) {esb:.2e} of max|ref|')
+    assert e32 <= 5e-6                                       # K up to 2304 products per output
+    assert esb <= max(2 * e32, 1e-6), f'split bf16 {esb:.2e} vs fp32 kernel {e32:.2e}'
+    assert maxabs(ysb, y32) / scale <= 4e-6
+
+
+def test_five_by_five_split_convs_when_forced(model_a):
+    """The 5x5 variants (decoder stride 1, encoder stride 2) are built too and selected with conv_sb = 2."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    x = torch.from_numpy(dense_like((4, 256, 23, 30), 950))
+    skip = torch.from_numpy(dense_like((4, 256, 23, 30), 951))
+    with torch.no_grad():
+        ref = O.upsample_conv_layer(skip + x, sd[O.P + 'decoders.0.1.conv2d.weight'], sd[O.P + 'decoders.0.1.conv2d.bias'])
+    m.set_tuning('conv_sb', 2)
+    try:
+        y = ops.decoder(m, 0, x.cuda(), skip.cuda())
+    finally:
+        m.set_tuning('conv_sb', 1)
+    assert maxabs(y, ref) <= 1e-4

@@ -350,3 +350,24 @@ def test_single_rank_rccl_broadcast_through_build_replicated_model(monkeypatch):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's multi-rank path end to end (rank 0 packs, rank 1 allocates the packed layout and receives the image by
+    the collective, both reconstruct and check their frames against the reference fixture), two processes on this one
+    GPU with the gloo backend: what the 8-GPU run does over RCCL."""
+    import json, os, subprocess, sys, socket
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, BDE_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--pipeline', '2',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['verified'] is True and d['verification']['max_abs_err'] <= 2e-4
