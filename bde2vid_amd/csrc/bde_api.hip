@@ -472,7 +472,7 @@ struct bde_model {
     PackedLayer head, pred_dummy;
     std::vector<PackedLayer> enc, gx, lstm, lstm8, dec;   // enc/gx/lstm: G=2 (fwd,bwd); lstm8 = the 8-channel-workgroup packing
     std::vector<AttnLevel> attn;
-    long predw_off = -1, predb_off = -1;
+    long predw_off = -1, predb_off = -1, zero_off = -1;
     // Workspace slots: slot 0 always; with pipeline depth 2 consecutive forward calls alternate between
     // two workspaces and two internal streams, so the latency-bound attention chain of one sequence
     // overlaps the batched convolutions of the next (the sequences are independent, bde2vid.py:31).
@@ -780,6 +780,7 @@ static int build_packed(bde_model* m) {
         std::copy(w, w + bc, ar.host.begin() + m->predw_off);
         m->predb_off = ar.alloc(1);
         ar.host[m->predb_off] = b[0];
+        m->zero_off = ar.alloc(64);                 // 256 bytes of zeros (conv_sb.h: out-of-image pixels)
     }
     return BDE_OK;
 }
@@ -875,6 +876,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
             b.wpk = m->P(pl.sb_off);
             b.w_gs = pl.sb_sz;
             b.nchunks = pl.sb_chunks;
+            b.zeros = m->P(m->zero_off);
             b.in_ns = (long)pl.sb_chunks * cc.Hs * cc.Ws * SB_PIX_BYTES / 4;
             b.in_gs = grouped_in ? b.in_ns * cc.N : 0;
             bool launched = false;

@@ -71,6 +71,7 @@ struct ConvArgs {
     const float* pred_head;  // [N][Cout][Ho*Wo] or nullptr
     float* pred_out;         // [N][Ho*Wo]
     int pred_sigmoid;
+    const float* zeros;      // >= 16 bytes of zeros in device memory (source of out-of-image pixels for LDS-DMA staging)
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU
