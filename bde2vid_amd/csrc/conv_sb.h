@@ -258,11 +258,10 @@ static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long h
     return BDE_OK;
 }
 
-template <int KS, int STRIDE>
-static int conv_sb_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launched) {
-    // one decomposition: 2 x 2 waves of 64 output channels x 64 pixels; pixel tiles aligned to image rows when a row is
-    // at least 3/4 of a tile, linear over rows otherwise
-    constexpr int MT = 2, NT = 2, WM = 2, WN = 2, BN = WN * NT * 32;
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN>
+static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* launched) {
+    // pixel tiles aligned to image rows when a row is at least 3/4 of a tile, linear over rows otherwise
+    constexpr int BN = WN * NT * 32;
     *launched = false;
     int best_rt = 0;
     const double fill_lin = (double)a.Ho * a.Wo / ((double)cdiv(a.Ho * a.Wo, BN) * BN);
@@ -271,11 +270,20 @@ static int conv_sb_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launch
     if (fill_row >= fill_lin - 0.1) best_rt = rt;
     a.row_tiles = best_rt;
     const long halo = conv_sb_halo_pixels(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, best_rt);
-    const long items = (halo * 6 + 255) / 256;
+    const long items = (halo * 6 + 64 * WM * WN - 1) / (64 * WM * WN);
     if (halo * SB_LDS_PITCH > 150 * 1024 || items > 16) return BDE_OK;      // the caller falls back to the fp32 kernels
     *launched = true;
     if (items <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8>(a, G, stream, halo);
     return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16>(a, G, stream, halo);
+}
+
+template <int KS, int STRIDE>
+static int conv_sb_launch_ks(const ConvArgs& a, int G, hipStream_t stream, bool* launched) {
+    // 128 output channels x 128 pixels per workgroup either way.  Four waves of 32 channels x 128 pixels share the pixel
+    // fragments through LDS and each stream their own weight fragments (12 KB per tap and workgroup from L2); 2 x 2 waves
+    // of 64 x 64 fetch every weight fragment twice (24 KB per tap), which is what saturated the L1 return path.
+    if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2>(a, G, stream, launched);
+    return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1>(a, G, stream, launched);
 }
 
 int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched) {

@@ -1,14 +1,12 @@
 #!/usr/bin/env python3
-"""End to end on one GPU, the way the reference's eval_models_seq.py drives its model, with this build's
-pieces: a recording's native event columns -> one voxel grid per between-frames window (on the device) ->
-padded to a multiple of 2**num_encoders -> the model on chunks of subseq_L frames -> cropped frames.
+"""End to end on one GPU, the way the reference's eval_model (eval_models_seq.py:147-282) drives its model, with this
+build's pieces: a recording (event columns resident in HBM, bde2vid_amd.recording.Recording = the reference's
+DynamicH5Dataset) -> one voxel grid per between-frames window (on the device) -> padded to a multiple of 2**num_encoders
+-> the model on chunks of subseq_L frames -> cropped frames -> MSE / SSIM against the recording's images (on the device).
 
-The recording here is synthetic (the HDF5 container needs h5py, which is not part of this build):
+The recording here is synthetic; with h5py installed a real file opens with `bde2vid_amd.recording.open_recording(path)`:
 
-    python examples/reconstruct_recording.py [--frames 32] [--height 180] [--width 240] [--checkpoint model.pth]
-
-With a real file the four columns are `f['events/xs'][:]`, `ys`, `ts`, `ps` and the window boundaries the
-frames' `event_idx` attributes (data_loader/h5_dataset.py:262-275,410-415 in the reference)."""
+    python examples/reconstruct_recording.py [--frames 32] [--height 180] [--width 240] [--checkpoint model.pth]"""
 import argparse
 import os
 import sys
@@ -29,10 +27,10 @@ def main():
     ap.add_argument('--checkpoint', default=None, help="a reference checkpoint {'state_dict','meta':{'cfg'}}")
     args = ap.parse_args()
 
-    from bde2vid_amd import canonical
-    from bde2vid_amd.events import events_to_voxel_windows
+    from bde2vid_amd import canonical, metrics
     from bde2vid_amd.harness import reconstruct_sequence
-    from bde2vid_amd.synth import synthetic_recording
+    from bde2vid_amd.recording import Recording
+    from bde2vid_amd.synth import synthetic_recording_with_frames
 
     device = torch.device('cuda:0')
     if args.checkpoint:
@@ -47,19 +45,22 @@ def main():
 
     H, W, T = args.height, args.width, args.frames
     n = T * (H * W // 2)
-    xs, ys, ts, ps, _ = synthetic_recording(n, H, W, 4, seed=1)
-    event_idx = np.arange(T + 1, dtype=np.int64) * (n // T)          # one window per frame
+    rec = Recording(arrays=synthetic_recording_with_frames(n, H, W, T + 1, seed=1), num_bins=cfg.num_bins,
+                    voxel_method={'method': 'between_frames'}, device=device)       # len(rec) == T items
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    grids = events_to_voxel_windows(xs, ys, ts, ps, event_idx, cfg.num_bins, sensor_size=(H, W), device=device)
-    voxels = [grids[t:t + 1] for t in range(T)]                      # T tensors [1, num_bins, H, W]
+    grids = rec.voxels(range(len(rec)))                              # [T, num_bins, H, W], one launch
+    voxels = [grids[t:t + 1] for t in range(len(rec))]
     frames = reconstruct_sequence(model, voxels, subseq_L=args.subseq)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = torch.cat(frames)                                          # [T, 1, H, W] in (0, 1)
-    print(f'{T} frames of {H}x{W} from {n} events in {dt * 1e3:.1f} ms (first call: includes workspace setup); '
-          f'output range [{float(out.min()):.3f}, {float(out.max()):.3f}], mean {float(out.mean()):.3f}')
+    gts = [torch.from_numpy(rec.get_frame(i)).float()[None, None] / 255 for i in range(len(rec))]
+    mean, _ = metrics.score_sequence(frames, gts)
+    print(f'{len(rec)} frames of {H}x{W} from {rec.num_events} events in {dt * 1e3:.1f} ms (first call: includes workspace setup); '
+          f'output range [{float(out.min()):.3f}, {float(out.max()):.3f}], mean {float(out.mean()):.3f}; against the (random) '
+          f'images of the synthetic recording: MSE {mean["mse"]:.4f}, SSIM {mean["ssim"]:.4f}')
     return out
 
 
