@@ -15,8 +15,9 @@
 //   weights      split once at pack time, in A-fragment order of the 32x32x16 MFMA:
 //                [co tile 32][chunk][tap][term][64 lanes][8]: lane l = W[32 tile + (l & 31)][16 chunk + 8 (l >> 5) + j][tap].
 // Workgroup = WM x WN waves, a wave = MT x NT tiles of 32 output channels x 32 pixels; per 16-channel chunk the halo tile of
-// the workgroup's BN pixels is staged global -> registers -> LDS (112-byte pixel pitch: conflict-free 16-byte fragment
-// reads), the next chunk's loads in flight during the MFMAs; weight fragments go global (L2) -> registers one tap ahead.
+// the workgroup's BN pixels is staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, which is what lets the
+// weight fragments be double-buffered and a third workgroup fit a CU; 112-byte pixel pitch: conflict-free 16-byte
+// fragment reads), the workgroups of a CU covering each other's staging; weight fragments go L2 -> registers one tap ahead.
 // Epilogue = generic_epilogue of conv_mfma.h (bias, ReLU / ReLU6, residuals; same D layout as the fp32 32x32x2 MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -89,7 +90,6 @@ static inline long split_bf16_bytes(long N, int C, long HW) { return N * cdiv(C,
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2, TAPS = KS * KS;
-    constexpr int NTH = 64 * WM * WN;
     constexpr int BN = WN * NT * 32;
     extern __shared__ __align__(16) unsigned char sb_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,38 +136,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     const int C16 = a.nchunks;
     const long plane = (long)a.Hs * a.Ws * SB_PIX_BYTES;                  // bytes of one 16-channel chunk of a frame
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (g * a.in_gs + n * a.in_ns) * 4;
-    // staging items of this thread: 16-byte piece q of halo pixel (r, c)
-    const int nitems = R * IW * 6;
+    // Halo staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no staging registers): the
+    // tile is R * IW pixels x 7 sixteen-byte slots (6 of data + the pad slot); block b = 64 consecutive slots = 1 KiB of LDS
+    // = one wave instruction, the waves take blocks wave, wave + NW, ...  A lane's source is its pixel's piece, or 16 bytes
+    // of zeros for pixels outside the image and for the pad slot.
+    constexpr int NW = WM * WN;
+    const int nslots = R * IW * 7;
+    const int nblk = (nslots + 63) >> 6;
     unsigned goff[MAXI];
-    int loff[MAXI];
     unsigned vmask = 0;
-    {
-        const float inv = 1.0f / (float)(IW * 6);
 #pragma unroll
-        for (int it = 0; it < MAXI; ++it) {
-            const int i = tid + it * NTH;
-            const int r = (int)(((float)i + 0.5f) * inv);
-            const int rem = i - r * IW * 6;
-            const int c = rem / 6, q = rem - c * 6;
-            const int iy = iy0 + r, ix = ix0 + c;
-            const bool item = i < nitems;
-            const bool in_img = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            loff[it] = item ? (r * IW + c) * SB_LDS_PITCH + q * 16 : -1;
-            goff[it] = (item && in_img) ? (unsigned)((iy * a.Ws + ix) * SB_PIX_BYTES + q * 16) : 0u;
-            if (item && in_img) vmask |= 1u << it;
-        }
+    for (int it = 0; it < MAXI; ++it) {
+        const int i = (wave + it * NW) * 64 + lane;
+        const int px = i / 7, q = i - px * 7;
+        const int r = px / IW, c = px - r * IW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool ok = i < nslots && q < 6 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        goff[it] = ok ? (unsigned)((iy * a.Ws + ix) * SB_PIX_BYTES + q * 16) : 0u;
+        if (ok) vmask |= 1u << it;
     }
-    sbf4 sv[MAXI];
-    auto stage_load = [&](int c16) {
+    const unsigned char* zero16 = reinterpret_cast<const unsigned char*>(a.zeros);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage = [&](int c16) {
         const unsigned char* cb = inb + c16 * plane;
 #pragma unroll
-        for (int it = 0; it < MAXI; ++it)
-            sv[it] = ((vmask >> it) & 1u) ? *reinterpret_cast<const sbf4*>(cb + goff[it]) : sbf4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto stage_store = [&]() {
-#pragma unroll
-        for (int it = 0; it < MAXI; ++it)
-            if (loff[it] >= 0) *reinterpret_cast<sbf4*>(sb_lds + loff[it]) = sv[it];
+        for (int it = 0; it < MAXI; ++it) {
+            const int blk = wave_u + it * NW;
+            if (blk < nblk) {
+                const unsigned char* src = ((vmask >> it) & 1u) ? cb + goff[it] : zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sb_lds + blk * 1024), 16, 0, 0);
+            }
+        }
     };
     // weight fragments: [co tile][chunk][tap][term][64][8] bf16
     const int cot0 = (blockIdx.y * WM + wm) * MT;
@@ -177,21 +177,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     for (int m = 0; m < MT; ++m)
         wfr[m] = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) + ((long)min(cot0 + m, ncot - 1) * C16 * TAPS * 3) * 64 + lane;
 
-    stage_load(0);
     for (int c16 = 0; c16 < C16; ++c16) {
+        __syncthreads();                                   // every wave is done with the previous chunk's tile
+        stage(c16);
+        sb8 af[2][MT][3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) af[0][m][k] = wfr[m][((long)c16 * TAPS * 3 + k) * 64];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA blocks (and the first fragments) have landed
         __syncthreads();
-        stage_store();
-        __syncthreads();
-        if (c16 + 1 < C16) stage_load(c16 + 1);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            // (two workgroups per CU: the other one's MFMAs cover these fragments' way from L2)
-            sb8 af[1][MT][3];
-            constexpr int cur = 0;
+            const int cur = tap & 1;
+            if (tap + 1 < TAPS) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) af[0][m][k] = wfr[m][(((long)c16 * TAPS + tap) * 3 + k) * 64];
+                    for (int k = 0; k < 3; ++k) af[cur ^ 1][m][k] = wfr[m][(((long)c16 * TAPS + tap + 1) * 3 + k) * 64];
+            }
             const int ky = tap / KS, kx = tap - ky * KS;
             sb8 bfr[NT][3];
 #pragma unroll
@@ -246,7 +250,7 @@ static inline long conv_sb_halo_pixels(int KS, int STRIDE, int BN, int Win, int 
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
 static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long halo_px) {
     constexpr int BN = WN * NT * 32;
-    const size_t lds = (size_t)halo_px * SB_LDS_PITCH;
+    const size_t lds = ((size_t)halo_px * SB_LDS_PITCH + 1023) / 1024 * 1024;     // whole 1-KiB DMA blocks
     auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI>;
     static unsigned char raised[BDE_MAX_DEVICES];
     if (lds > 64 * 1024 && first_use_on_device(raised))
@@ -270,11 +274,13 @@ static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* lau
     if (fill_row >= fill_lin - 0.1) best_rt = rt;
     a.row_tiles = best_rt;
     const long halo = conv_sb_halo_pixels(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, best_rt);
-    const long items = (halo * 6 + 64 * WM * WN - 1) / (64 * WM * WN);
-    if (halo * SB_LDS_PITCH > 150 * 1024 || items > 16) return BDE_OK;      // the caller falls back to the fp32 kernels
+    const long blocks = (halo * 7 + 63) / 64;                               // 1-KiB DMA blocks of the tile
+    const long per_wave = (blocks + WM * WN - 1) / (WM * WN);
+    if (halo * SB_LDS_PITCH > 78 * 1024 || per_wave > 24) return BDE_OK;    // (two workgroups per CU) else the fp32 kernels
     *launched = true;
-    if (items <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8>(a, G, stream, halo);
-    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16>(a, G, stream, halo);
+    if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8>(a, G, stream, halo);
+    if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16>(a, G, stream, halo);
+    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 24>(a, G, stream, halo);
 }
 
 template <int KS, int STRIDE>
