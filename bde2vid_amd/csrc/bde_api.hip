@@ -860,9 +860,11 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         a.pred_sigmoid = m->cfg.activation;
     }
     if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
-    // (measured at the canonical sizes: 3x3 gate convs 728 / 632 us against 954 / 989 us on the fp32 matrix path, 5x5
-    //  convs 708 against 638 us: the 5x5 ones stay on the fp32 kernels unless conv_sb == 2)
-    if (m->conv_sb && (pl.KS == 3 || m->conv_sb >= 2) && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
+    // (measured at the canonical sizes: 3x3 gate convs 627 / 513 / 510 us against 954 / 954 / 989 us on the fp32 matrix
+    //  path; of the 5x5 convolutions only the stride-1 ones with >= 128 output channels gain: 585 against 633 us)
+    const bool sb_shape = (pl.KS == 3 || (pl.KS == 5 && cc.stride == 1) || m->conv_sb >= 2) &&
+                          conv_sb_fits(pl.KS, cc.stride, pl.Cout, a.Win, a.Ho, a.Wo);
+    if (m->conv_sb && sb_shape && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
         // split the input into three bf16 terms (SB16), then the convolution on the bf16 matrix cores; the small
         // launches (a few frames of a small map) stay on the fp32 kernels
         Workspace& ws = const_cast<bde_model*>(m)->W();

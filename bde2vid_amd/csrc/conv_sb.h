@@ -246,6 +246,18 @@ static inline long conv_sb_halo_pixels(int KS, int STRIDE, int BN, int Win, int 
     return best;
 }
 
+// Would conv_sb_launch take this convolution?  (asked before the input is split: mirrors conv_sb_launch_shape)
+static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
+    if (!((KS == 3 && stride == 1) || (KS == 5 && (stride == 1 || stride == 2)))) return false;
+    if (Cout < 128) return false;                       // a workgroup spans 128 output channels (4 waves x 32)
+    constexpr int BN = 128;
+    const double fill_lin = (double)Ho * Wo / ((double)cdiv(Ho * Wo, BN) * BN);
+    const int rt = cdiv(Wo, BN);
+    const double fill_row = (double)Wo / ((double)rt * BN);
+    const long halo = conv_sb_halo_pixels(KS, stride, BN, Win, Ho, Wo, fill_row >= fill_lin - 0.1 ? rt : 0);
+    return halo * SB_LDS_PITCH <= 78 * 1024 && (halo * 7 + 63) / 64 <= 4 * 24;
+}
+
 #ifdef BDE_CONV_TU
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
 static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long halo_px) {
