@@ -66,3 +66,26 @@ def test_five_by_five_split_convs_when_forced(model_a):
     finally:
         m.set_tuning('conv_sb', 1)
     assert maxabs(y, ref) <= 1e-4
+
+
+def test_gate_conv_random_shapes(model_a):
+    """Seeded sweep: odd widths (tiles straddling rows), maps narrower / wider than a pixel tile, few and many frames, on
+    both sides of the launch-size threshold under which the fp32 kernels are used."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    rng = np.random.default_rng(7)
+    for case in range(8):
+        level = int(rng.integers(0, 3))
+        C = cfg.enc_out(level)
+        H, W = int(rng.integers(5, 70)), int(rng.integers(5, 150))
+        N = int(rng.integers(1, 6))
+        x = torch.from_numpy(dense_like((2, N, C, H, W), 1000 + case))
+        ref = []
+        for d, name in enumerate(('forward_encoder', 'backward_encoder')):
+            w = sd[f'{O.P}{name}.{level}.recurrent_block.Gates.weight'][:, :C]
+            b = sd[f'{O.P}{name}.{level}.recurrent_block.Gates.bias']
+            ref.append(F.conv2d(x[d], w, b, padding=1))
+        ref = torch.stack(ref)
+        y = ops.gate_conv(m, level, x.cuda())
+        assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), f'case {case}: level {level} N={N} {H}x{W}'

@@ -186,3 +186,26 @@ def test_recurrent_step_at_canonical_widths(model_a, hw, level):
         h, c = ops.recurrent_conv(m, level, direction, torch.stack(xs).cuda())
         assert maxabs(h, torch.stack(ref)) <= TOL
         assert maxabs(c, state[1]) <= TOL
+
+
+def test_random_shapes_level2_chain_vs_oracle(model_a):
+    """Seeded sweep over map sizes / batch / missing frames for the fragment-layout chain (csrc/wideblock.h): token counts
+    that are not multiples of 16 (the last fragment tile is partial), every padding split, dilated blocks with uncovered
+    pixels, zero frames at the sequence ends."""
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    rng = np.random.default_rng(20261004)
+    for case in range(8):
+        H, W = int(rng.integers(7, 40)), int(rng.integers(7, 40))
+        B = int(rng.integers(1, 3))
+        bufs = [torch.from_numpy(dense_like((B, 256, H, W), 800 + 10 * case + d)) for d in range(3)]
+        drop = int(rng.integers(0, 4))
+        if drop in (1, 3):
+            bufs[0] = None
+        if drop in (2, 3):
+            bufs[2] = None
+        first = int(rng.integers(0, 4))
+        n = int(rng.integers(1, min(3, cfg.depths[2] - first) + 1))
+        ref = oracle_blocks(cfg, sd, bufs, first, n, level=2)
+        y = ops.dframe_attention(m, 2, [None if b is None else b.cuda() for b in bufs], first, n)
+        assert maxabs(y, ref) <= TOL, f'case {case}: {B}x256x{H}x{W}, blocks {first}..{first + n - 1}, drop {drop}'
