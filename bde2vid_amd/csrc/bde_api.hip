@@ -445,6 +445,7 @@ struct Workspace {
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     float* sb = nullptr;          // split-bf16 image of the input of the convolution in flight (conv_sb.h)
+    std::vector<float*> hsb, ghb; // per level: hidden state as SB16, two buffers [2][2 dirs][B][C16][hw] / h-part of the gates [2][B][4C][hw]
     long sb_bytes = 0;
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
     bool warm = false;
@@ -471,6 +472,7 @@ struct bde_model {
     long dev_numel = 0;
     PackedLayer head, pred_dummy;
     std::vector<PackedLayer> enc, gx, lstm, lstm8, dec;   // enc/gx/lstm: G=2 (fwd,bwd); lstm8 = the 8-channel-workgroup packing
+    std::vector<PackedLayer> lstm_sb;                     // h-part of the gates, split-bf16 packing only (conv_sb.h)
     std::vector<AttnLevel> attn;
     long predw_off = -1, predb_off = -1, zero_off = -1;
     // Workspace slots: slot 0 always; with pipeline depth 2 consecutive forward calls alternate between
@@ -507,6 +509,7 @@ struct bde_model {
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
     int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
+    int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
@@ -516,6 +519,8 @@ struct bde_model {
     int cin(int l) const { return cfg.basechannels << l; }
     int cout(int l) const { return cfg.basechannels << (l + 1); }
     const float* P(long off) const { return dev + off; }
+    long lstm_sb_off(int l) const { return (size_t)l < lstm_sb.size() ? lstm_sb[l].sb_off : -1; }
+    long zero_off_long() const { return zero_off; }
 };
 
 namespace bde {
@@ -608,6 +613,7 @@ static int build_packed(bde_model* m) {
     m->gx.assign(L, PackedLayer());
     m->lstm.assign(L, PackedLayer());
     m->lstm8.assign(L, PackedLayer());
+    m->lstm_sb.assign(L, PackedLayer());
     m->dec.assign(L, PackedLayer());
     m->attn.assign(L, AttnLevel());
     {
@@ -634,6 +640,11 @@ static int build_packed(bde_model* m) {
         pack_split_bf16(ar, m->gx[l], {&gxd[0], &gxd[1]});
         m->lstm[l] = pack_lstm16(ar, {&gh[0], &gh[1]});
         m->lstm8[l] = pack_lstm8(ar, {&gh[0], &gh[1]});
+        {
+            PackedLayer& ps = m->lstm_sb[l];
+            ps.Cin = co; ps.Cout = 4 * co; ps.KS = 3; ps.G = 2;
+            pack_split_bf16(ar, ps, {&gh[0], &gh[1]});
+        }
     }
     const int D = c.frame_num, heads = c.num_heads;
     const int tbl_rows = (2 * D - 1) * 13 * 13;
@@ -921,6 +932,7 @@ static int ws_alloc(Workspace& ws, float** p, long numel) {
 
 static bool winblock_ok(const bde_model* m, int l);
 static bool wide_ok(const bde_model* m, int l);
+static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w);
 
 static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     Workspace& ws = m->W();
@@ -933,6 +945,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     BDE_TRY(ws_alloc(ws, &ws.head, TB * c.basechannels * H * W));
     BDE_TRY(ws_alloc(ws, &ws.out, TB * H * W));
     ws.xenc.assign(L, nullptr); ws.gx.assign(L, nullptr); ws.hseq.assign(L, nullptr); ws.cst.assign(L, nullptr);
+    ws.hsb.assign(L, nullptr); ws.ghb.assign(L, nullptr);
     ws.merged.assign(L, nullptr); ws.mergedT.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
     long max_attn = 0;
     for (int l = 0; l < L; ++l) {
@@ -942,6 +955,10 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.gx[l], 2 * TB * 4 * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.hseq[l], 2 * TB * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.cst[l], 2 * (long)B * C * hw));
+        if (lstm_sb_ok(m, l, B, H >> (l + 1), W >> (l + 1))) {
+            BDE_TRY(ws_alloc(ws, &ws.hsb[l], 2 * split_bf16_bytes(2L * B, (int)C, hw) / 4 + 4));
+            BDE_TRY(ws_alloc(ws, &ws.ghb[l], 2L * B * 4 * C * hw));
+        }
         BDE_TRY(ws_alloc(ws, &ws.merged[l], TB * C * hw));
         if (c.depths[l] > 0) {
             if (winblock_ok(m, l)) {
@@ -1028,12 +1045,81 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     return BDE_OK;
 }
 
+// The recurrent step on the bf16 matrix cores: h-part of the gates by conv_sb_kernel on the SB16 image of h_prev, then the
+// pointwise tail as an element-wise kernel that also writes the next step's SB16 h.  Built, parity-tested
+// (set_tuning("lstm_sb", 1)) and measured at the canonical config: a step is one small launch (368 / 176 / 96 workgroups at
+// levels 0 / 1 / 2), each workgroup walks its 4 / 8 / 16 channel chunks with the halo staging exposed (one or two
+// workgroups per CU; two LDS buffers leave a single workgroup per CU and two rounds at level 0): 69 us of convolution +
+// 16.5 us of pointwise kernel per step against 65 us for lstm16_step_kernel.  Off by default.
+static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w) {
+    if (m->lstm_sb_mode == 0 || !m->conv_sb) return false;
+    const int C = m->cout(l);
+    if (m->lstm_sb_off(l) < 0 || !conv_sb_fits(3, 1, 4 * C, w, h, w)) return false;
+    if (m->lstm_sb_mode == 1) return true;
+    const long wgs = cdivl((long)h * w, 128) * cdivl(4 * C, 128) * 2 * B;
+    return wgs >= 160 && cdiv(C, 16) <= 8;
+}
+
+static int run_recurrent_steps_sb(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
+    Workspace& ws = m->W();
+    const int C = m->cout(l);
+    const long TB = (long)T * B, hw = (long)h * w;
+    const PackedLayer& pl = m->lstm_sb[l];
+    float* hs = ws.hseq[l];
+    const long dstride = TB * C * hw, fs = (long)B * C * hw;
+    const long sbf = split_bf16_bytes(2L * B, C, hw) / 4;          // floats of one SB16 hidden-state buffer (both directions)
+    for (int st = 0; st < T; ++st) {
+        const int tf = st, tb = T - 1 - st;
+        ProfScope ps(m, pname("lstm", l), s);
+        float* hsb_prev = ws.hsb[l] + ((st + 1) & 1) * sbf;
+        float* hsb_next = ws.hsb[l] + (st & 1) * sbf;
+        if (st > 0) {
+            ConvArgs a;
+            memset(&a, 0, sizeof a);
+            a.in = hsb_prev;
+            a.in_ns = (long)pl.sb_chunks * hw * SB_PIX_BYTES / 4;
+            a.in_gs = a.in_ns * B;
+            a.wpk = m->P(pl.sb_off);
+            a.w_gs = pl.sb_sz;
+            a.bias = m->P(m->zero_off_long());                       // the gates' bias rides in gx
+            a.bias_gs = 0;
+            a.out = ws.ghb[l];
+            a.out_ns = (long)4 * C * hw;
+            a.out_gs = a.out_ns * B;
+            a.res1_ns = a.res2_ns = a.out_ns;
+            a.N = B; a.Cin = C; a.Hin = a.Hs = h; a.Win = a.Ws = w; a.Cout = 4 * C; a.Ho = h; a.Wo = w;
+            a.nchunks = pl.sb_chunks;
+            a.act = ACT_NONE;
+            a.zeros = m->P(m->zero_off);
+            bool launched = false;
+            BDE_TRY(conv_sb_launch(3, 1, a, 2, s, &launched));
+            BDE_REQUIRE(launched, "recurrent step: the split-bf16 convolution does not fit %dx%d", h, w);
+        }
+        LstmPointArgs p;
+        memset(&p, 0, sizeof p);
+        p.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
+        p.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - p.gx;
+        p.gx_ns = (long)4 * C * hw;
+        p.gh = st > 0 ? ws.ghb[l] : nullptr;
+        p.cstate = ws.cst[l];
+        p.hout = hs + (long)tf * fs;
+        p.h_gs = (hs + dstride + (long)tb * fs) - p.hout;
+        p.h_ns = (long)C * hw;
+        p.hsb = reinterpret_cast<unsigned short*>(hsb_next);
+        p.C = C; p.B = B; p.HW = hw;
+        p.first = st == 0;
+        BDE_TRY(lstm_point_launch(p, s));
+    }
+    return BDE_OK;
+}
+
 static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int B, int H, int W, hipStream_t s,
                                bool enc_done = false) {
     Workspace& ws = m->W();
     const int C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
     if (!enc_done && !(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
+    if (!(m->debug_skip & 4) && ws.hsb[l] != nullptr) return run_recurrent_steps_sb(m, l, T, B, h, w, s);
     // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
     const PackedLayer& pl = m->lstm[l];
     float* hs = ws.hseq[l];
@@ -1807,6 +1893,12 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_sb") {
+        if (m->lstm_sb_mode != (int)value)
+            for (auto& w : m->wslots) w.release();
+        m->lstm_sb_mode = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "fuse_pred") { m->fuse_pred = (int)value; return BDE_OK; }
     if (std::string(key) == "fused_min_tiles") { m->fused_min_tiles = value; return BDE_OK; }
     if (std::string(key) == "pw_batched") { m->tune.pw_batched = (int)value; return BDE_OK; }
@@ -1837,6 +1929,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "winblock") *value = m->winblock;
     else if (k == "wide") *value = m->wide;
     else if (k == "conv_sb") *value = m->conv_sb;
+    else if (k == "lstm_sb") *value = m->lstm_sb_mode;
     else if (k == "packed_numel") *value = m->dev_numel;
     else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
     return BDE_OK;

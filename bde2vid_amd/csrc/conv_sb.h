@@ -84,10 +84,78 @@ int split_bf16(const float* in, void* out, long N, int C, long HW, hipStream_t s
 #else
 int split_bf16(const float* in, void* out, long N, int C, long HW, hipStream_t s);   // conv_tu.hip
 #endif
+// ConvLSTM pointwise tail for the split-bf16 recurrent step (submodules.py:320-332): gates = gx (x-part incl. bias) + gh
+// (h-part, from conv_sb_kernel; nullptr at the first step, h = 0), chunk order i, f, o, g; c = sigma(f) c + sigma(i) tanh(g);
+// h = sigma(o) tanh(c).  Writes c in place, h as fp32 planes (the level's hidden sequence) and as SB16 (the next step's
+// convolution input).  grid (ceil(HW / 128), C16, 2 * B), thread = (pixel, half of a 16-channel chunk).
+struct LstmPointArgs {
+    const float* gx;       // direction g, frame n: gx + g * gx_gs + n * gx_ns, [4C][HW]
+    const float* gh;       // [2][B][4C][HW] or nullptr
+    float* cstate;         // [2][B][C][HW]
+    float* hout;           // direction g, frame n: hout + g * h_gs + n * h_ns, [C][HW]
+    unsigned short* hsb;   // [2][B][C16][HW][3][16]
+    long gx_gs, gx_ns, h_gs, h_ns;
+    int C, B;
+    long HW;
+    int first;             // 1: c_prev = 0 as well
+};
+#ifdef BDE_CONV_TU
+__device__ __forceinline__ float sb_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+__device__ __forceinline__ float sb_tanh(float v) { return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -2.8853900817779268f)) - 1.f; }
+__global__ __launch_bounds__(256) void lstm_point_kernel(const LstmPointArgs a) {
+    const int half = threadIdx.x & 1;
+    const long p = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int c16 = blockIdx.y;
+    const int g = blockIdx.z / a.B, n = blockIdx.z - g * a.B;
+    if (p >= a.HW) return;
+    const int C16 = gridDim.y, C = a.C;
+    const float* gx = a.gx + g * a.gx_gs + n * a.gx_ns;
+    const float* gh = a.gh ? a.gh + ((long)(g * a.B + n) * 4 * C) * a.HW : nullptr;
+    float* cs = a.cstate + ((long)(g * a.B + n) * C) * a.HW;
+    float* ho = a.hout + g * a.h_gs + n * a.h_ns;
+    unsigned short t[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = c16 * 16 + half * 8 + j;
+        float h = 0.f;
+        if (ch < C) {
+            const long o = (long)ch * a.HW + p;
+            float vi = gx[o], vf = gx[o + (long)C * a.HW], vo = gx[o + 2L * C * a.HW], vg = gx[o + 3L * C * a.HW];
+            if (gh) { vi += gh[o]; vf += gh[o + (long)C * a.HW]; vo += gh[o + 2L * C * a.HW]; vg += gh[o + 3L * C * a.HW]; }
+            const float cp = a.first ? 0.f : cs[o];
+            const float c = sb_sigmoid(vf) * cp + sb_sigmoid(vi) * sb_tanh(vg);
+            h = sb_sigmoid(vo) * sb_tanh(c);
+            cs[o] = c;
+            ho[o] = h;
+        }
+        sb_split3(h, t[0][j], t[1][j], t[2][j]);
+    }
+    unsigned short* o = a.hsb + ((((long)(g * a.B + n) * C16 + c16) * a.HW + p) * 3) * 16 + half * 8;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint4 v;
+        v.x = t[k][0] | ((unsigned)t[k][1] << 16);
+        v.y = t[k][2] | ((unsigned)t[k][3] << 16);
+        v.z = t[k][4] | ((unsigned)t[k][5] << 16);
+        v.w = t[k][6] | ((unsigned)t[k][7] << 16);
+        *reinterpret_cast<uint4*>(o + k * 16) = v;
+    }
+}
+int lstm_point_launch(const LstmPointArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_point_kernel, dim3((unsigned)cdivl(a.HW, 128), cdiv(a.C, 16), 2 * a.B), dim3(256), 0, s, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+#else
+int lstm_point_launch(const LstmPointArgs& a, hipStream_t s);   // conv_tu.hip
+#endif
+
 static inline long split_bf16_bytes(long N, int C, long HW) { return N * cdiv(C, 16) * HW * SB_PIX_BYTES; }
 
 // a.in = SB16 activations (as float*), a.wpk = split packed weights; group / frame strides of `in` in BYTES / 4 (floats).
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
+// DB: two halo buffers in LDS, the next chunk's DMA in flight during the MFMAs of the current one -- for the small launches
+// of the recurrent step, where a CU holds one or two workgroups and nobody else covers the staging.
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2, TAPS = KS * KS;
     constexpr int BN = WN * NT * 32;
@@ -157,15 +225,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     }
     const unsigned char* zero16 = reinterpret_cast<const unsigned char*>(a.zeros);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int tile_bytes = nblk * 1024;                    // one halo buffer
     auto stage = [&](int c16) {
         const unsigned char* cb = inb + c16 * plane;
+        unsigned char* dstb = sb_lds + (DB ? (c16 & 1) * tile_bytes : 0);
 #pragma unroll
         for (int it = 0; it < MAXI; ++it) {
             const int blk = wave_u + it * NW;
             if (blk < nblk) {
                 const unsigned char* src = ((vmask >> it) & 1u) ? cb + goff[it] : zero16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(sb_lds + blk * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dstb + blk * 1024), 16, 0, 0);
             }
         }
     };
@@ -177,9 +247,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     for (int m = 0; m < MT; ++m)
         wfr[m] = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) + ((long)min(cot0 + m, ncot - 1) * C16 * TAPS * 3) * 64 + lane;
 
+    if (DB) stage(0);
     for (int c16 = 0; c16 < C16; ++c16) {
-        __syncthreads();                                   // every wave is done with the previous chunk's tile
-        stage(c16);
+        if (!DB) {
+            __syncthreads();                               // every wave is done with the previous chunk's tile
+            stage(c16);
+        }
+        const unsigned char* tile = sb_lds + (DB ? (c16 & 1) * tile_bytes : 0);
         sb8 af[2][MT][3];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -187,6 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             for (int k = 0; k < 3; ++k) af[0][m][k] = wfr[m][((long)c16 * TAPS * 3 + k) * 64];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA blocks (and the first fragments) have landed
         __syncthreads();
+        if (DB && c16 + 1 < C16) stage(c16 + 1);            // (every wave left the other buffer before that barrier)
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int cur = tap & 1;
@@ -202,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    bfr[t][k] = *reinterpret_cast<const sb8*>(sb_lds + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
+                    bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -259,11 +334,11 @@ static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, i
 }
 
 #ifdef BDE_CONV_TU
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB>
 static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long halo_px) {
     constexpr int BN = WN * NT * 32;
-    const size_t lds = ((size_t)halo_px * SB_LDS_PITCH + 1023) / 1024 * 1024;     // whole 1-KiB DMA blocks
-    auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI>;
+    const size_t lds = (DB ? 2 : 1) * (((size_t)halo_px * 7 + 63) / 64 * 1024);   // whole 1-KiB DMA blocks (7 slots per pixel)
+    auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI, DB>;
     static unsigned char raised[BDE_MAX_DEVICES];
     if (lds > 64 * 1024 && first_use_on_device(raised))
         BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -290,9 +365,15 @@ static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* lau
     const long per_wave = (blocks + WM * WN - 1) / (WM * WN);
     if (halo * SB_LDS_PITCH > 78 * 1024 || per_wave > 24) return BDE_OK;    // (two workgroups per CU) else the fp32 kernels
     *launched = true;
-    if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8>(a, G, stream, halo);
-    if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16>(a, G, stream, halo);
-    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 24>(a, G, stream, halo);
+    // few workgroups (the recurrent step): double-buffered halo, one workgroup per CU covers its own staging
+    const long wgs = (long)(best_rt > 0 ? a.Ho * best_rt : cdiv(a.Ho * a.Wo, BN)) * cdiv(a.Cout, WM * MT * 32) * G * a.N;
+    if (KS == 3 && wgs <= 768 && halo * SB_LDS_PITCH * 2 <= 150 * 1024) {
+        if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, true>(a, G, stream, halo);
+        if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, true>(a, G, stream, halo);
+    }
+    if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, false>(a, G, stream, halo);
+    if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, false>(a, G, stream, halo);
+    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 24, false>(a, G, stream, halo);
 }
 
 template <int KS, int STRIDE>

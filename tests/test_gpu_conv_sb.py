@@ -89,3 +89,19 @@ def test_gate_conv_random_shapes(model_a):
         ref = torch.stack(ref)
         y = ops.gate_conv(m, level, x.cuda())
         assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), f'case {case}: level {level} N={N} {H}x{W}'
+
+
+def test_recurrent_step_on_split_bf16(model_a):
+    """The opt-in form of the recurrent step (h-part of the gates by conv_sb_kernel + an element-wise ConvLSTM tail,
+    set_tuning('lstm_sb', 1)) against the default lstm16 kernel: RecurrentConv of level 0, four steps, both directions."""
+    from bde2vid_amd import ops
+    cfg, sd, m = model_a
+    x = torch.from_numpy(dense_like((4, 1, cfg.enc_in(0), 184, 240), 1100)).cuda()
+    ref = [ops.recurrent_conv(m, 0, d, x) for d in (0, 1)]
+    m.set_tuning('lstm_sb', 1)
+    try:
+        got = [ops.recurrent_conv(m, 0, d, x) for d in (0, 1)]
+    finally:
+        m.set_tuning('lstm_sb', 0)
+    for (h0, c0), (h1, c1) in zip(ref, got):
+        assert maxabs(h1, h0) <= 2e-5 and maxabs(c1, c0) <= 2e-5
