@@ -716,7 +716,7 @@ static int build_packed(bde_model* m) {
             }
             if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
                 // winblock.h: keys reordered query frame first, score tile (query tile i, key tile j) in the
-                // C/D register order of the 16x16x4 MFMA: [head][i][j][r][lane], key = 16j + 4(lane>>4) + r
+                // C/D register order of the 16x16x4 MFMA: [head][i][j][lane][r], key = 16j + 4(lane>>4) + r
                 ab.biasF_off = ar.alloc((long)heads * 4 * WB_NT * 256);
                 float* bfp = ar.host.data() + ab.biasF_off;
                 bt = ar.host.data() + ab.bias_off;               // (the arena may have moved: alloc() grows a std::vector)
@@ -739,7 +739,7 @@ static int build_packed(bde_model* m) {
                                         }
                                         v = bt[((long)h * N + n) * 49 + mq];
                                     }
-                                    bfp[((((long)h * 4 + qi) * WB_NT + j) * 4 + r) * 64 + ln] = v;
+                                    bfp[((((long)h * 4 + qi) * WB_NT + j) * 64 + ln) * 4 + r] = v;
                                 }
             }
             DenseLayer proj;

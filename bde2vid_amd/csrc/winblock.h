@@ -58,7 +58,7 @@ struct WinArgs {
     const float *wproj, *bproj;                 // packed16 [4][16][64], [64]
     const float *wfc1, *bfc1, *sfc1;            // packed16 [16][16][64], [256], [256]
     const float *wfc2, *bfc2;                   // packed16 [4][64][64], [64]
-    const float* biasF;             // [16 heads][4 query tiles][10 key tiles][4][64]: score-tile order, log2(e) folded,
+    const float* biasF;             // [16 heads][4 query tiles][10 key tiles][64 lanes][4]: a lane's four C-operand values of a score tile as one 16-byte load, log2(e) folded,
                                     // keys beyond D*49 = -1e30
     int nslots;                     // D
     int H, W, Hp, Wp, pt, pl, nWw, nWin, dilated;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
             const float mean = s1 * (1.f / WB_C);
             const float var = fmaxf(s2 * (1.f / WB_C) - mean * mean, 0.f);
             ST[u] = mean;
-            ST[160 + u] = 1.0f / sqrtf(var + 1e-5f);
+            ST[160 + u] = __builtin_amdgcn_rsqf(var + 1e-5f);
         }
     }
     wb_sync();
@@ -280,25 +280,24 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
             for (int j = 0; j < WB_NT; ++j) kf[j] = KL[(j * WB_C + h * WB_HD + g4) * 16 + col];
 #pragma unroll
             for (int i = 0; i < NQT; ++i) qf[i] = QL[(i * WB_C + h * WB_HD + g4) * 16 + col];
-            const float* bf = a.biasF + (long)h * 4 * WB_NT * 256 + lane;
+            const f32x4* bf = reinterpret_cast<const f32x4*>(a.biasF + (long)h * 4 * WB_NT * 256) + lane;
             // Half a query tile (5 key tiles = 20 scores per lane) at a time, the bias of the next half in
             // flight meanwhile; every lane keeps its own running maximum over its quarter of the keys and
             // the four quarters of all query tiles are merged at the end.
             constexpr int HT = WB_NT / 2;
             f32x4 sc[2][HT];
 #pragma unroll
-            for (int j = 0; j < HT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sc[0][j][r] = bf[(j * 4 + r) * 64];
+            for (int j = 0; j < HT; ++j) sc[0][j] = bf[j * 64];
             // The 49th query would be a tile of its own (a quarter of the softmax work for one token): it is taken
             // with the KEYS on the lanes instead, lane (col, g4) and register r <-> key 16*col + 4*g4 + r (col < 10).
             // Its bias values sit in column 0 of query tile 3 of the table.
             float s48[4];
             {
                 const int jt = min(col, WB_NT - 1);
-                const float* b48 = a.biasF + ((long)(h * 4 + 3) * WB_NT + jt) * 256 + g4 * 16;
+                // (tile (3, jt): the values of query column 0 and key quarter g4 sit in lane 16 * g4)
+                const f32x4 b48 = *(reinterpret_cast<const f32x4*>(a.biasF + ((long)(h * 4 + 3) * WB_NT + jt) * 256) + g4 * 16);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s48[r] = col < WB_NT ? b48[r * 64] : -1e30f;
+                for (int r = 0; r < 4; ++r) s48[r] = col < WB_NT ? b48[r] : -1e30f;
             }
             const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
             float pm[NQT], pl[NQT], po[NQT][4];                        // per query tile: max, sum, p*v of this lane's keys
@@ -311,9 +310,7 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
                     const int nt = (i * 2 + hf + 1);                     // next half-tile overall
                     if (nt < 2 * NQT) {
 #pragma unroll
-                        for (int j = 0; j < HT; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sc[nx][j][r] = bf[((nt * HT + j) * 4 + r) * 64];
+                        for (int j = 0; j < HT; ++j) sc[nx][j] = bf[(nt * HT + j) * 64];
                     }
                     f32x4 vb[2][4];
 #pragma unroll
@@ -497,7 +494,9 @@ __global__ __launch_bounds__(1024) void winblock_kernel(const WinArgs a) {
 #pragma unroll
             for (int k4 = 0; k4 < 16; ++k4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[k4], bq[k4], acc, 0, 0, 0);
             const float mu = s1 * (1.f / WB_C);
-            const float rs = 1.0f / sqrtf(fmaxf(s2 * (1.f / WB_C) - mu * mu, 0.f) + 1e-5f);
+            // (v_rsq_f32, 1 ulp: the IEEE sqrt + divide pair costs ~50 vector instructions per token tile in a phase that is
+            //  vector-issue bound beside its MFMAs)
+            const float rs = __builtin_amdgcn_rsqf(fmaxf(s2 * (1.f / WB_C) - mu * mu, 0.f) + 1e-5f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) HID[(i * WB_HID + row0 + r) * 16 + col] = gelu_f(rs * (acc[r] - mu * ss[r]) + bb[r]);
         }
