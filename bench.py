@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak (= fp32 vector peak)
+SPLIT_BF16_PEAK_TFLOPS = 2500.0 / 6   # fp32-equivalent work on the bf16 matrix cores: dense bf16 peak / six MFMAs per fp32 block (csrc/conv_sb.h)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
 ATOMIC_PEAK_GBPS = 1300.0       # MI355X_MICROARCH.md, global float atomics: ~1.3 TB/s of added bytes chip-wide
 PMC_FILE = os.path.join(REPO, 'profiles', 'r2_pmc.json')
@@ -441,9 +442,16 @@ def main():
             kernels[nm] = dict(ms_per_forward=ms / n_eager, launches_per_forward=cnt / n_eager, avg_us=ms / cnt * 1e3,
                                flops_per_launch=fl, achieved=total_fl / (ms * 1e-3) / 1e12, bound=bound)
         fwd_ms = spans.get('forward', (0.0, 0))[0] / max(n_eager, 1)
+        # spans whose contraction runs as split bf16 (csrc/conv_sb.h: the 3x3 gate convolutions and the 5x5 stride-1 ones with
+        # >= 128 output channels, when the tile fits; spans include the SB16 conversion of the input)
+        sb_on = model.get_info('conv_sb') >= 1
         for nm, k in kernels.items():
             k['share'] = k['ms_per_forward'] / fwd_ms if fwd_ms > 0 else None
-            k['frac'] = k['achieved'] / FP32_MFMA_PEAK_TFLOPS
+            split = sb_on and (nm.startswith('gates_x') or nm == 'dec_conv0')
+            k['peak'] = SPLIT_BF16_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            if split:
+                k['bound'] = 'mfma (bf16 matrix cores, 6 MFMAs per fp32 block)'
+            k['frac'] = k['achieved'] / k['peak']
         dom = max(kernels, key=lambda n: kernels[n]['ms_per_forward'])
         dk = kernels[dom]
         kre, desc = describe_span(dom)
@@ -484,12 +492,14 @@ def main():
                        'parallelism': f'{world} replica(s), sequences sharded, 1 RCCL weight broadcast; per GPU '
                                       f'{args.pipeline} independent sequence(s) in flight'},
             'roofline': {'kernel': f'{dom}: {desc}', 'rocprof_kernel': kre, 'bound': dk['bound'],
-                         'achieved': dk['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': dk['frac'],
+                         'achieved': dk['achieved'], 'peak': dk['peak'], 'unit': 'TFLOP/s', 'frac': dk['frac'],
                          'traffic': traffic, 'traffic_source': prov,
                          'launches_per_forward': dk['launches_per_forward'], 'avg_us': dk['avg_us'],
                          'flops_per_launch': dk['flops_per_launch'], 'share_of_forward': dk['share'],
                          'chosen': 'the kernel with the largest total time among the HIP-event spans of this run',
                          'stages': stages,
+                         'stages_note': 'fp32-equivalent flops / time against the fp32 matrix peak (157.3); the gate convolutions inside '
+                                        'encoder_stage run as split bf16 on the bf16 matrix cores (peak/6 = 417), see kernels[*].peak',
                          'kernels': {nm: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()}
                                      for nm, kk in sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_forward'])},
                          'eager_forward_ms': fwd_ms,
