@@ -17,7 +17,8 @@
 // Workgroup = WM x WN waves, a wave = MT x NT tiles of 32 output channels x 32 pixels; per 16-channel chunk the halo tile of
 // the workgroup's BN pixels is staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, which is what lets the
 // weight fragments be double-buffered and a third workgroup fit a CU; 112-byte pixel pitch: conflict-free 16-byte
-// fragment reads), the workgroups of a CU covering each other's staging; weight fragments go L2 -> registers one tap ahead.
+// fragment reads), the workgroups of a CU covering each other's staging; weight fragments go L2 -> registers two (3x3) or four (5x5)
+// taps ahead.
 // Epilogue = generic_epilogue of conv_mfma.h (bias, ReLU / ReLU6, residuals; same D layout as the fp32 32x32x2 MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -247,6 +248,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     for (int m = 0; m < MT; ++m)
         wfr[m] = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) + ((long)min(cot0 + m, ncot - 1) * C16 * TAPS * 3) * 64 + lane;
 
+    // Weight fragments run PF taps ahead of the MFMAs that use them, in a ring of RING = PF + 1 register sets; the taps
+    // of a chunk are a whole number of ring turns, so the ring position of a tap is a compile-time constant and the
+    // stream simply continues across chunks (the fragments of consecutive (chunk, tap) pairs are consecutive in memory).
+    // A launch with one or two workgroups per CU (the recurrent step) has nobody else to cover an L2 round trip.
+    constexpr int RING = (TAPS % 3 == 0) ? 3 : 5, PF = RING - 1;
+    static_assert(TAPS % RING == 0, "ring position of a tap must not depend on the chunk");
+    const int S = C16 * TAPS;                               // (chunk, tap) pairs of the launch
+    sb8 af[RING][MT][3];
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) af[q][m][k] = wfr[m][((long)min(q, S - 1) * 3 + k) * 64];
     if (DB) stage(0);
     for (int c16 = 0; c16 < C16; ++c16) {
         if (!DB) {
@@ -254,22 +269,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             stage(c16);
         }
         const unsigned char* tile = sb_lds + (DB ? (c16 & 1) * tile_bytes : 0);
-        sb8 af[2][MT][3];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) af[0][m][k] = wfr[m][((long)c16 * TAPS * 3 + k) * 64];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA blocks (and the first fragments) have landed
+        // this wave's DMA blocks have landed; with DB they are older than the PF taps of fragments still in flight
+        if (DB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PF * MT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (DB && c16 + 1 < C16) stage(c16 + 1);            // (every wave left the other buffer before that barrier)
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int cur = tap & 1;
-            if (tap + 1 < TAPS) {
+            const int cur = tap % RING, nxt = (tap + PF) % RING;
+            {
+                const long sp = min(c16 * TAPS + tap + PF, S - 1);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) af[cur ^ 1][m][k] = wfr[m][(((long)c16 * TAPS + tap + 1) * 3 + k) * 64];
+                    for (int k = 0; k < 3; ++k) af[nxt][m][k] = wfr[m][(sp * 3 + k) * 64];
             }
             const int ky = tap / KS, kx = tap - ky * KS;
             sb8 bfr[NT][3];
