@@ -216,6 +216,7 @@ struct PackedLayer {
     int G = 1;                                  // groups packed back to back (fwd, bwd)
     long sb_off = -1, sb_sz = 0;                // split-bf16 packing (conv_sb.h), floats; one group = sb_sz
     int sb_chunks = 0;                          // 16-channel chunks
+    mutable int sb_used = 0;                    // the latest launch of this layer ran on conv_sb_kernel (bde_get_info "sb_*")
 };
 
 struct Arena {
@@ -871,10 +872,10 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         a.pred_sigmoid = m->cfg.activation;
     }
     if (pl.KS == 1) return pw_launch_auto(a, pl.G, s);
-    // (measured at the canonical sizes: 3x3 gate convs 627 / 513 / 510 us against 954 / 954 / 989 us on the fp32 matrix
-    //  path; of the 5x5 convolutions only the stride-1 ones with >= 128 output channels gain: 585 against 633 us)
-    const bool sb_shape = (pl.KS == 3 || (pl.KS == 5 && cc.stride == 1) || m->conv_sb >= 2) &&
-                          conv_sb_fits(pl.KS, cc.stride, pl.Cout, a.Win, a.Ho, a.Wo);
+    // (measured at the canonical sizes, us: 3x3 gate convs 530 / 497 / 505 against 954 / 954 / 989 on the fp32 matrix path;
+    //  5x5: decoder 0 488 vs 633, decoder 1 (64 channels) 502 vs 641, encoder 1 / 2 (stride 2) 271 / 300 vs 345 / 335;
+    //  conv_sb_pick has no shape for 32 output channels or for the stride-2 halo of level 0, those stay on the fp32 kernels)
+    const bool sb_shape = conv_sb_fits(pl.KS, cc.stride, pl.Cout, a.Win, a.Ho, a.Wo);
     if (m->conv_sb && sb_shape && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
         // split the input into three bf16 terms (SB16), then the convolution on the bf16 matrix cores; the small
         // launches (a few frames of a small map) stay on the fp32 kernels
@@ -894,9 +895,11 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
             b.in_gs = grouped_in ? b.in_ns * cc.N : 0;
             bool launched = false;
             BDE_TRY(conv_sb_launch(pl.KS, cc.stride, b, pl.G, s, &launched));
+            pl.sb_used = launched ? 1 : 0;
             if (launched) return BDE_OK;
         }
     }
+    pl.sb_used = 0;
     return conv_launch_best(pl.KS, cc.stride, a, pl.G, s);
 }
 
@@ -1931,6 +1934,15 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "conv_sb") *value = m->conv_sb;
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;
     else if (k == "packed_numel") *value = m->dev_numel;
+    else if (k.compare(0, 3, "sb_") == 0 && k.size() >= 5 && k.back() >= '0' && k.back() - '0' < m->L) {
+        // did the latest launch of that layer run as split bf16 (conv_sb.h)?  "sb_enc<l>", "sb_gx<l>", "sb_dec<j>"
+        const int i = k.back() - '0';
+        const std::string what = k.substr(3, k.size() - 4);
+        if (what == "enc") *value = m->enc[i].sb_used;
+        else if (what == "gx") *value = m->gx[i].sb_used;
+        else if (what == "dec") *value = m->dec[i].sb_used;
+        else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
+    }
     else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
     return BDE_OK;
 }

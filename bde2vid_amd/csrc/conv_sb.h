@@ -334,16 +334,35 @@ static inline long conv_sb_halo_pixels(int KS, int STRIDE, int BN, int Win, int 
     return best;
 }
 
-// Would conv_sb_launch take this convolution?  (asked before the input is split: mirrors conv_sb_launch_shape)
-static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
-    if (!((KS == 3 && stride == 1) || (KS == 5 && (stride == 1 || stride == 2)))) return false;
-    if (Cout < 128) return false;                       // a workgroup spans 128 output channels (4 waves x 32)
-    constexpr int BN = 128;
+// Workgroup shapes (output channels x pixels; all four waves):
+//   SB_128x128  four waves of 32 x 128 sharing the pixel fragments (the 3x3 gate convolutions, decoder 0)
+//   SB_128x64   four waves of 32 x 64: maps narrower than 128 pixels / stride-2 halos that do not fit at 128 (5x5 only)
+//   SB_64x128   2 x 2 waves of 32 x 64 for 64 output channels (5x5 stride 1: decoder 1)
+enum { SB_NONE = 0, SB_128x128, SB_128x64, SB_64x128 };
+// pixel tiles aligned to image rows when a row is at least 3/4 of a tile (row_tiles > 0), linear over rows otherwise
+static inline int conv_sb_row_tiles(int BN, int Ho, int Wo) {
     const double fill_lin = (double)Ho * Wo / ((double)cdiv(Ho * Wo, BN) * BN);
     const int rt = cdiv(Wo, BN);
     const double fill_row = (double)Wo / ((double)rt * BN);
-    const long halo = conv_sb_halo_pixels(KS, stride, BN, Win, Ho, Wo, fill_row >= fill_lin - 0.1 ? rt : 0);
-    return halo * SB_LDS_PITCH <= 78 * 1024 && (halo * 7 + 63) / 64 <= 4 * 24;
+    return fill_row >= fill_lin - 0.1 ? rt : 0;
+}
+static inline bool conv_sb_tile_fits(int KS, int stride, int BN, int Win, int Ho, int Wo) {
+    const long halo = conv_sb_halo_pixels(KS, stride, BN, Win, Ho, Wo, conv_sb_row_tiles(BN, Ho, Wo));
+    return halo * SB_LDS_PITCH <= 78 * 1024 && (halo * 7 + 63) / 64 <= 4 * 24;       // two workgroups per CU; <= 24 DMA blocks per wave
+}
+// Which shape conv_sb_launch takes for this convolution (asked before the input is split)
+static inline int conv_sb_pick(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
+    if (!((KS == 3 && stride == 1) || (KS == 5 && (stride == 1 || stride == 2)))) return SB_NONE;
+    if (Cout >= 128) {
+        if (conv_sb_tile_fits(KS, stride, 128, Win, Ho, Wo)) return SB_128x128;
+        if (KS == 5 && conv_sb_tile_fits(KS, stride, 64, Win, Ho, Wo)) return SB_128x64;
+        return SB_NONE;
+    }
+    if (Cout == 64 && KS == 5 && stride == 1 && conv_sb_tile_fits(KS, stride, 128, Win, Ho, Wo)) return SB_64x128;
+    return SB_NONE;
+}
+static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
+    return conv_sb_pick(KS, stride, Cout, Win, Ho, Wo) != SB_NONE;
 }
 
 #ifdef BDE_CONV_TU
@@ -364,14 +383,9 @@ static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long h
 
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN>
 static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* launched) {
-    // pixel tiles aligned to image rows when a row is at least 3/4 of a tile, linear over rows otherwise
     constexpr int BN = WN * NT * 32;
     *launched = false;
-    int best_rt = 0;
-    const double fill_lin = (double)a.Ho * a.Wo / ((double)cdiv(a.Ho * a.Wo, BN) * BN);
-    const int rt = cdiv(a.Wo, BN);
-    const double fill_row = (double)a.Wo / ((double)rt * BN);
-    if (fill_row >= fill_lin - 0.1) best_rt = rt;
+    const int best_rt = conv_sb_row_tiles(BN, a.Ho, a.Wo);
     a.row_tiles = best_rt;
     const long halo = conv_sb_halo_pixels(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, best_rt);
     const long blocks = (halo * 7 + 63) / 64;                               // 1-KiB DMA blocks of the tile
@@ -391,11 +405,21 @@ static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* lau
 
 template <int KS, int STRIDE>
 static int conv_sb_launch_ks(const ConvArgs& a, int G, hipStream_t stream, bool* launched) {
-    // 128 output channels x 128 pixels per workgroup either way.  Four waves of 32 channels x 128 pixels share the pixel
-    // fragments through LDS and each stream their own weight fragments (12 KB per tap and workgroup from L2); 2 x 2 waves
-    // of 64 x 64 fetch every weight fragment twice (24 KB per tap), which is what saturated the L1 return path.
-    if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2>(a, G, stream, launched);
-    return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1>(a, G, stream, launched);
+    // SB_128x128: four waves of 32 channels x 128 pixels share the pixel fragments through LDS and each stream their own
+    // weight fragments (12 KB per tap and workgroup from L2); 2 x 2 waves of 64 x 64 fetch every weight fragment twice
+    // (24 KB per tap), which is what saturated the L1 return path.
+    const int shape = conv_sb_pick(KS, STRIDE, a.Cout, a.Win, a.Ho, a.Wo);
+    if (shape == SB_128x128) {
+        if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2>(a, G, stream, launched);
+        return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1>(a, G, stream, launched);
+    }
+    if constexpr (KS == 5) {
+        if (shape == SB_128x64) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 4, 1>(a, G, stream, launched);
+        if constexpr (STRIDE == 1)
+            if (shape == SB_64x128) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 2, 2>(a, G, stream, launched);
+    }
+    *launched = false;
+    return BDE_OK;
 }
 
 int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched) {

@@ -442,12 +442,13 @@ def main():
             kernels[nm] = dict(ms_per_forward=ms / n_eager, launches_per_forward=cnt / n_eager, avg_us=ms / cnt * 1e3,
                                flops_per_launch=fl, achieved=total_fl / (ms * 1e-3) / 1e12, bound=bound)
         fwd_ms = spans.get('forward', (0.0, 0))[0] / max(n_eager, 1)
-        # spans whose contraction runs as split bf16 (csrc/conv_sb.h: the 3x3 gate convolutions and the 5x5 stride-1 ones with
-        # >= 128 output channels, when the tile fits; spans include the SB16 conversion of the input)
-        sb_on = model.get_info('conv_sb') >= 1
+        # spans whose contraction ran as split bf16 (csrc/conv_sb.h; the library says which: bde_get_info "sb_gx<l>" / "sb_enc<l>" /
+        # "sb_dec<j>"; spans include the SB16 conversion of the input)
+        sb_key = {'gates_x': 'sb_gx', 'enc_conv': 'sb_enc', 'dec_conv': 'sb_dec'}
         for nm, k in kernels.items():
             k['share'] = k['ms_per_forward'] / fwd_ms if fwd_ms > 0 else None
-            split = sb_on and (nm.startswith('gates_x') or nm == 'dec_conv0')
+            mm = re.fullmatch(r'(gates_x|enc_conv|dec_conv)(\d)', nm)
+            split = bool(mm) and model.get_info(sb_key[mm.group(1)] + mm.group(2)) == 1     # what the library launched
             k['peak'] = SPLIT_BF16_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
             if split:
                 k['bound'] = 'mfma (bf16 matrix cores, 6 MFMAs per fp32 block)'
@@ -498,8 +499,8 @@ def main():
                          'flops_per_launch': dk['flops_per_launch'], 'share_of_forward': dk['share'],
                          'chosen': 'the kernel with the largest total time among the HIP-event spans of this run',
                          'stages': stages,
-                         'stages_note': 'fp32-equivalent flops / time against the fp32 matrix peak (157.3); the gate convolutions inside '
-                                        'encoder_stage run as split bf16 on the bf16 matrix cores (peak/6 = 417), see kernels[*].peak',
+                         'stages_note': 'fp32-equivalent flops / time against the fp32 matrix peak (157.3); the convolutions whose '
+                                        'kernels[*].peak is 416.7 ran as split bf16 on the bf16 matrix cores (dense bf16 peak / 6)',
                          'kernels': {nm: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()}
                                      for nm, kk in sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_forward'])},
                          'eager_forward_ms': fwd_ms,

@@ -51,8 +51,8 @@ def test_gate_conv_error_against_float64(model_a, level, hw, N):
     assert maxabs(ysb, y32) / scale <= 4e-6
 
 
-def test_five_by_five_split_convs_when_forced(model_a):
-    """The 5x5 variants (decoder stride 1, encoder stride 2) are built too and selected with conv_sb = 2."""
+def test_five_by_five_split_conv_of_decoder0(model_a):
+    """Decoder 0 (5x5 stride 1, 256 -> 128 channels) on the 128 x 128 shape."""
     from bde2vid_amd import ops
     from oracle import bde2vid_oracle as O
     cfg, sd, m = model_a
@@ -60,12 +60,42 @@ def test_five_by_five_split_convs_when_forced(model_a):
     skip = torch.from_numpy(dense_like((4, 256, 23, 30), 951))
     with torch.no_grad():
         ref = O.upsample_conv_layer(skip + x, sd[O.P + 'decoders.0.1.conv2d.weight'], sd[O.P + 'decoders.0.1.conv2d.bias'])
-    m.set_tuning('conv_sb', 2)
-    try:
-        y = ops.decoder(m, 0, x.cuda(), skip.cuda())
-    finally:
-        m.set_tuning('conv_sb', 1)
+    y = ops.decoder(m, 0, x.cuda(), skip.cuda())
     assert maxabs(y, ref) <= 1e-4
+
+
+def test_decoder1_takes_the_64_channel_shape(model_a):
+    """Decoder 1 (5x5 stride 1, 128 -> 64 channels) runs on 2 x 2 waves of 32 x 64 by default once a launch has >= 16384
+    output pixels; odd map sizes put the tiles across image rows."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    for (N, H, W, seed) in ((4, 46, 60, 960), (3, 37, 51, 962)):
+        x = torch.from_numpy(dense_like((N, 128, H, W), seed))
+        skip = torch.from_numpy(dense_like((N, 128, H, W), seed + 1))
+        with torch.no_grad():
+            ref = O.upsample_conv_layer(skip + x, sd[O.P + 'decoders.1.1.conv2d.weight'], sd[O.P + 'decoders.1.1.conv2d.bias'])
+        y = ops.decoder(m, 1, x.cuda(), skip.cuda())
+        m.set_tuning('conv_sb', 0)
+        try:
+            y32 = ops.decoder(m, 1, x.cuda(), skip.cuda())
+        finally:
+            m.set_tuning('conv_sb', 1)
+        assert maxabs(y, ref) <= 1e-4, (N, H, W)
+        assert maxabs(y, y32) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_stride2_encoder_conv(model_a):
+    """The stride-2 encoder convolution of level 1 (64 -> 128 channels) on four waves of 32 x 64."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    x = torch.from_numpy(dense_like((8, 64, 92, 120), 970))
+    for d, name in enumerate(('forward_encoder', 'backward_encoder')):
+        with torch.no_grad():
+            ref = O.conv_layer(x, sd[f'{O.P}{name}.1.conv.conv2d.weight'], sd[f'{O.P}{name}.1.conv.conv2d.bias'], 2, 'relu')
+        y = ops.encoder_conv(m, 1, d, x.cuda())
+        assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), name
 
 
 def test_gate_conv_random_shapes(model_a):
