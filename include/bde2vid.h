@@ -113,7 +113,9 @@ int bde_wait_outputs(bde_model* m, void* stream);
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 /* Read back the state the measurement has to be honest about: "debug_skip" (non-zero = stages skipped, results
  * invalid), "graph" (0 also after a failed capture), "graphs_live" (workspaces replaying a captured launch
- * sequence), "pipeline", "winblock", "device", "packed_numel".  Settings are per model object. */
+ * sequence), "pipeline", "winblock", "wide", "conv_sb", "lstm_sb", "last_stream", "device", "packed_numel"; and which
+ * convolutions the latest forward ran as split bf16 (csrc/conv_sb.h): "sb_enc<l>", "sb_gx<l>", "sb_dec<j>" (0 / 1).
+ * Settings are per model object. */
 int bde_get_info(const bde_model* m, const char* key, int64_t* value);
 
 /* Diagnostics: resident workgroups per CU the runtime reports for a named kernel (-1 = unknown). */

@@ -25,8 +25,8 @@ SPAN_KERNELS = [
     ('lstm2', r'lstm16_step_kernel<2, 32, 1'),
     ('gates_x*', r'conv_sb_kernel<3, 1|conv_vec_kernel<3, 1'),
     ('split_bf16', r'split_bf16_kernel'),
-    ('enc_conv*', r'conv_vec_kernel<5, 2'),
-    ('dec_conv*+head', r'conv_vec_kernel<5, 1'),
+    ('enc_conv*', r'conv_sb_kernel<5, 2|conv_vec_kernel<5, 2'),
+    ('dec_conv*+head', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1'),
     ('gates_x2(dword path)', r'conv_mfma_kernel<3, 1'),
     ('chain(pw_gemm)', r'pw_gemm_kernel'),
     ('chain_core2', r'attn_mfma16_kernel'),
