@@ -446,6 +446,8 @@ struct Workspace {
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     float* sb = nullptr;          // split-bf16 image of the input of the convolution in flight (conv_sb.h)
+    float* sb2 = nullptr;         // split-bf16 encoder output of a level, written by the encoder conv's epilogue for its gate conv
+    long sb2_bytes = 0;
     std::vector<float*> hsb, ghb; // per level: hidden state as SB16, two buffers [2][2 dirs][B][C16][hw] / h-part of the gates [2][B][4C][hw]
     long sb_bytes = 0;
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
@@ -509,6 +511,7 @@ struct bde_model {
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
+    int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
     int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
@@ -828,7 +831,17 @@ struct ConvCall {
     int cout_rows = -1;          // override (kvall uses all rows)
     const float* pred_head = nullptr;   // fused predI (conv_mfma.h): set pred_out to enable
     float* pred_out = nullptr;
+    float* out_sb = nullptr;     // store the result as SB16 here INSTEAD of fp32 planes in `out` (conv_mfma.h sb_out)
+    long out_sb_gs = 0;          // its group stride, floats
+    bool in_sb = false;          // `in` already is the SB16 image (in_gs in floats of that image): conv_sb or fail
 };
+
+// Will run_conv take the split-bf16 kernels for this layer at this size?  (decided before the producer of its input runs)
+static bool conv_takes_sb(const bde_model* m, const PackedLayer& pl, int stride, int N, int Hs, int Ws) {
+    const int pad = pl.KS / 2;
+    const int Ho = (Hs + 2 * pad - pl.KS) / stride + 1, Wo = (Ws + 2 * pad - pl.KS) / stride + 1;
+    return m->conv_sb && pl.sb_off >= 0 && conv_sb_fits(pl.KS, stride, pl.Cout, Ws, Ho, Wo) && (long)pl.G * N * Ho * Wo >= 16384;
+}
 
 static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     const PackedLayer& pl = *cc.pl;
@@ -864,6 +877,11 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.res1_gs = a.res2_gs = cc.out_gs;
     a.w_gs = pl.w_sz;
     a.bias_gs = pl.Cout;
+    if (cc.out_sb) {
+        a.sb_out = reinterpret_cast<unsigned short*>(cc.out_sb);
+        a.sb_out_ns = (long)cdiv(pl.Cout, 16) * a.Ho * a.Wo * 48;
+        a.sb_out_gs = cc.out_sb_gs * 2;
+    }
     if (cc.pred_out) {
         a.pred_w = m->P(m->predw_off);
         a.pred_b = m->P(m->predb_off);
@@ -875,29 +893,29 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     // (measured at the canonical sizes, us: 3x3 gate convs 530 / 497 / 505 against 954 / 954 / 989 on the fp32 matrix path;
     //  5x5: decoder 0 488 vs 633, decoder 1 (64 channels) 502 vs 641, encoder 1 / 2 (stride 2) 271 / 300 vs 345 / 335;
     //  conv_sb_pick has no shape for 32 output channels or for the stride-2 halo of level 0, those stay on the fp32 kernels)
-    const bool sb_shape = conv_sb_fits(pl.KS, cc.stride, pl.Cout, a.Win, a.Ho, a.Wo);
-    if (m->conv_sb && sb_shape && pl.sb_off >= 0 && !cc.pred_out && (long)pl.G * cc.N * a.Ho * a.Wo >= 16384) {
-        // split the input into three bf16 terms (SB16), then the convolution on the bf16 matrix cores; the small
-        // launches (a few frames of a small map) stay on the fp32 kernels
+    if (cc.in_sb || (!cc.pred_out && conv_takes_sb(m, pl, cc.stride, cc.N, cc.Hs, cc.Ws))) {
+        // split the input into three bf16 terms (SB16) unless its producer already wrote it that way, then the convolution
+        // on the bf16 matrix cores; the small launches (a few frames of a small map) stay on the fp32 kernels
         Workspace& ws = const_cast<bde_model*>(m)->W();
         const bool grouped_in = cc.in_gs != 0;
         const long frames = (grouped_in ? pl.G : 1) * (long)cc.N;
         const long need = split_bf16_bytes(frames, pl.Cin, (long)cc.Hs * cc.Ws);
-        if (ws.sb && need <= ws.sb_bytes) {
-            BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, s));
+        if (cc.in_sb || (ws.sb && need <= ws.sb_bytes)) {
+            if (!cc.in_sb) BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, s));
             ConvArgs b = a;
-            b.in = ws.sb;
+            b.in = cc.in_sb ? cc.in : ws.sb;
             b.wpk = m->P(pl.sb_off);
             b.w_gs = pl.sb_sz;
             b.nchunks = pl.sb_chunks;
             b.zeros = m->P(m->zero_off);
             b.in_ns = (long)pl.sb_chunks * cc.Hs * cc.Ws * SB_PIX_BYTES / 4;
-            b.in_gs = grouped_in ? b.in_ns * cc.N : 0;
+            b.in_gs = cc.in_sb ? cc.in_gs : (grouped_in ? b.in_ns * cc.N : 0);
             bool launched = false;
             BDE_TRY(conv_sb_launch(pl.KS, cc.stride, b, pl.G, s, &launched));
             pl.sb_used = launched ? 1 : 0;
             if (launched) return BDE_OK;
         }
+        if (cc.in_sb) return fail(BDE_ERR_UNSUPPORTED, "convolution on a split-bf16 input has no split-bf16 launch at this size");
     }
     pl.sb_used = 0;
     return conv_launch_best(pl.KS, cc.stride, a, pl.G, s);
@@ -997,6 +1015,10 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         }
         ws.sb_bytes = mx;
         BDE_TRY(ws_alloc(ws, &ws.sb, mx / 4 + 4));
+        long mx2 = 0;
+        for (int l = 0; l < L; ++l) mx2 = std::max(mx2, split_bf16_bytes(2 * TB, m->cout(l), (long)(H >> (l + 1)) * (W >> (l + 1))));
+        ws.sb2_bytes = mx2;
+        BDE_TRY(ws_alloc(ws, &ws.sb2, mx2 / 4 + 4));
     }
     if (max_attn > 0) {
         BDE_TRY(ws_alloc(ws, &ws.qkv, 3 * max_attn));
@@ -1033,6 +1055,15 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     e.act = ACT_RELU;
     e.in_gs = 0;
     e.out_gs = TB * C * hw;
+    // the gate convolution reads its input as SB16 (conv_sb.h): the encoder conv's epilogue then writes that image directly
+    // (6 B per element) and the fp32 planes + their conversion pass are skipped
+    const long sb_fs = (long)cdiv(C, 16) * hw * SB_PIX_BYTES / 4;         // floats of one SB16 frame
+    const bool fuse = m->fuse_enc_sb && C % 32 == 0 && conv_takes_sb(m, m->gx[l], 1, nf, h, w) &&
+                      ws.sb2 && split_bf16_bytes(2 * TB, C, hw) <= ws.sb2_bytes;
+    if (fuse) {
+        e.out_sb = ws.sb2 + (long)f0 * sb_fs;
+        e.out_sb_gs = TB * sb_fs;
+    }
     { ProfScope ps(m, pname("enc_conv", l), s); BDE_TRY(run_conv(m, e, s)); }
     // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
     ConvCall gxc;
@@ -1044,6 +1075,11 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     gxc.Ws = w;
     gxc.in_gs = TB * C * hw;
     gxc.out_gs = TB * 4 * C * hw;
+    if (fuse) {
+        gxc.in = ws.sb2 + (long)f0 * sb_fs;
+        gxc.in_gs = TB * sb_fs;
+        gxc.in_sb = true;
+    }
     { ProfScope ps(m, pname("gates_x", l), s); BDE_TRY(run_conv(m, gxc, s)); }
     return BDE_OK;
 }
@@ -1896,6 +1932,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_sb") {
         if (m->lstm_sb_mode != (int)value)
             for (auto& w : m->wslots) w.release();

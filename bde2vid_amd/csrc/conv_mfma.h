@@ -72,6 +72,10 @@ struct ConvArgs {
     float* pred_out;         // [N][Ho*Wo]
     int pred_sigmoid;
     const float* zeros;      // >= 16 bytes of zeros in device memory (source of out-of-image pixels for LDS-DMA staging)
+    // ---- split-bf16 output: when sb_out is set the result is stored ONLY as SB16 [G?][N][Cout/16][HW][3 terms][16] bf16
+    // (conv_sb.h: the input layout of the convolution that consumes it), not as fp32 planes; Cout % 32 == 0, no residuals
+    unsigned short* sb_out;
+    long sb_out_gs, sb_out_ns;   // group / frame strides in bf16 elements
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU
@@ -101,6 +105,20 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // Row of accumulator register r inside a 32x32 tile (cdna_hip_programming.md §3).
+// x = hi + mid + lo in three bf16 terms, round to nearest even (the same arithmetic as sb_split3 of conv_sb.h)
+__device__ __forceinline__ unsigned short sb_rne_dev(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void sb_split3_dev(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    hi = sb_rne_dev(x);
+    const float r1 = x - __builtin_bit_cast(float, (unsigned)hi << 16);
+    mid = sb_rne_dev(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, (unsigned)mid << 16);
+    lo = sb_rne_dev(r2);
+}
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // Shared epilogue of the generic contractions: LayerNorm fold, bias, activation, dilated-window
@@ -146,6 +164,36 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
             s += __shfl_xor(s, 32);
             s += pb;
             if ((lane >> 5) == 0 && pix[t] < p_end) po[p] = a.pred_sigmoid ? 1.f / (1.f + expf(-s)) : s;
+        }
+        return;
+    }
+    if (a.sb_out != nullptr) {
+        // a lane's registers 4q .. 4q+3 are four consecutive output channels (acc_row): 8 bytes of each of the three terms
+        static_assert(RPW % 4 == 0, "split-bf16 store takes registers in groups of four");
+        unsigned short* sbb = a.sb_out + g * a.sb_out_gs + n * a.sb_out_ns;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = pix[t];
+            if (p >= p_end) continue;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < RPW / 4; ++q) {
+                    const int co0 = (cot0 + m) * 32 + acc_row(r0 + 4 * q, lane);
+                    if (co0 >= a.Cout) continue;
+                    unsigned short hi[4], mid[4], lo[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = fin[m][t][4 * q + i];
+                        if (want_ln) v = rstd[t] * (v - mu[t] * sv[m][4 * q + i]);
+                        v = act_apply(v + bv[m][4 * q + i], a.act);
+                        sb_split3_dev(v, hi[i], mid[i], lo[i]);
+                    }
+                    unsigned short* d = sbb + ((long)(co0 >> 4) * HW + p) * 48 + (co0 & 15);
+                    *reinterpret_cast<uint2*>(d) = uint2{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16)};
+                    *reinterpret_cast<uint2*>(d + 16) = uint2{mid[0] | ((unsigned)mid[1] << 16), mid[2] | ((unsigned)mid[3] << 16)};
+                    *reinterpret_cast<uint2*>(d + 32) = uint2{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16)};
+                }
         }
         return;
     }

@@ -104,6 +104,10 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *              call of a shape; 0 launches eagerly.
  *   "fused_min_tiles": a level with at least this many 32-pixel tiles runs the post-softmax part of an
  *                      attention block as one fused kernel instead of three GEMM launches (default 160).
+ *   "conv_sb": 1 (default) runs the batched convolutions that have a split-bf16 shape (csrc/conv_sb.h) on the bf16
+ *              matrix cores with three-term split operands (fp32-equivalent); 0 keeps every convolution on the fp32 kernels.
+ *   "fuse_enc_sb": 1 (default) lets an encoder convolution store its result only as the split-bf16 image its gate
+ *              convolution reads; 0 writes fp32 planes and converts them in a pass of their own (same frames, bit for bit).
  *   "winblock": 1 (default) runs an attention block of a 64-channel / 16-head level as ONE launch
  *               (csrc/winblock.h); 0 keeps the split path (attention core + fused token kernel).
  *   "attn_mfma": 1 (default) uses the matrix-core attention core for head_dim 16 (csrc/attn_mfma.h).

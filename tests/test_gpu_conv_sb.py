@@ -98,6 +98,24 @@ def test_stride2_encoder_conv(model_a):
         assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), name
 
 
+def test_encoder_epilogue_writes_the_gate_conv_input(model_a):
+    """By default the encoder convolution stores its result only as the SB16 image its gate convolution reads
+    (conv_mfma.h sb_out; fp32 and split-bf16 encoder kernels alike).  The split is the same arithmetic as split_bf16_kernel's,
+    so the frames equal those of the unfused schedule bit for bit."""
+    from tests.util import golden_inputs
+    cfg, sd, m = model_a
+    xs = golden_inputs(6, 1, 5, 184, 240, 1234)
+    inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    y1 = torch.stack(m(inp))
+    m.set_tuning('fuse_enc_sb', 0)
+    try:
+        y0 = torch.stack(m(inp))
+    finally:
+        m.set_tuning('fuse_enc_sb', 1)
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y0, y1)
+
+
 def test_gate_conv_random_shapes(model_a):
     """Seeded sweep: odd widths (tiles straddling rows), maps narrower / wider than a pixel tile, few and many frames, on
     both sides of the launch-size threshold under which the fp32 kernels are used."""
