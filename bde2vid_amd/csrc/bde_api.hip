@@ -171,6 +171,62 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
         }
     }
 }
+// The same bilinear x2 of (a + b), stored as the SB16 image a split-bf16 decoder convolution reads (conv_sb.h) instead of fp32
+// planes: [N][C/16][2Hs][2Ws][3 terms][16 channels] bf16.  grid (ceil(4 Hs Ws / 128), C/16 chunks, N), thread = (output
+// pixel, half of the chunk): 2 x 2 source pixels of 8 channels of both tensors, three 16-byte stores.  Same expression and
+// weights per output as upsample2x_sum_kernel.
+__global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                   unsigned short* __restrict__ out, int C, int Hs, int Ws) {
+    const int Wo = 2 * Ws;
+    const long HWo = 4L * Hs * Ws, HWs = (long)Hs * Ws;
+    // (a wave = 64 consecutive pixels of one half: every plane load is one or two full 128-byte segments)
+    const int half = threadIdx.x >> 7;
+    const long p = (long)blockIdx.x * 128 + (threadIdx.x & 127);
+    if (p >= HWo) return;
+    const int c16 = blockIdx.y, C16 = gridDim.y;
+    const long n = blockIdx.z;
+    const int y = (int)(p / Wo), x = (int)(p - (long)y * Wo);
+    const int k = y >> 1, j = x >> 1;
+    const int ya = (y & 1) ? k : max(k - 1, 0), yb = (y & 1) ? min(k + 1, Hs - 1) : k;
+    const int xa = (x & 1) ? j : max(j - 1, 0), xb = (x & 1) ? min(j + 1, Ws - 1) : j;
+    float wyb = (y & 1) ? 0.25f : 0.75f, wxb = (x & 1) ? 0.25f : 0.75f;
+    if (ya == yb) wyb = 1.f;
+    if (xa == xb) wxb = 1.f;
+    const float wya = 1.f - wyb, wxa = 1.f - wxb;
+    const int iaa = ya * Ws + xa, iab = ya * Ws + xb, iba = yb * Ws + xa, ibb = yb * Ws + xb;
+    unsigned short t[3][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = c16 * 16 + half * 8 + q;
+        float o = 0.f;
+        if (c < C) {
+            const float* pa = a + (n * C + c) * HWs;
+            float vaa = pa[iaa], vab = pa[iab], vba = pa[iba], vbb = pa[ibb];
+            if (b) {
+                const float* pb = b + (n * C + c) * HWs;
+                vaa += pb[iaa]; vab += pb[iab]; vba += pb[iba]; vbb += pb[ibb];
+            }
+            o = wya * (wxa * vaa + wxb * vab) + wyb * (wxa * vba + wxb * vbb);
+        }
+        sb_split3(o, t[0][q], t[1][q], t[2][q]);
+    }
+    unsigned short* d = out + (((n * C16 + c16) * HWo + p) * 3) * 16 + half * 8;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        uint4 v;
+        v.x = t[kk][0] | ((unsigned)t[kk][1] << 16);
+        v.y = t[kk][2] | ((unsigned)t[kk][3] << 16);
+        v.z = t[kk][4] | ((unsigned)t[kk][5] << 16);
+        v.w = t[kk][6] | ((unsigned)t[kk][7] << 16);
+        *reinterpret_cast<uint4*>(d + kk * 16) = v;
+    }
+}
+static int upsample2x_sum_split(const float* a, const float* b, void* out_sb, int N, int C, int Hs, int Ws, hipStream_t s) {
+    hipLaunchKernelGGL(upsample2x_sum_split_kernel, dim3((unsigned)cdivl(4L * Hs * Ws, 128), cdiv(C, 16), (unsigned)N), dim3(256), 0, s,
+                       a, b, (unsigned short*)out_sb, C, Hs, Ws);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
 static int upsample2x_sum(const float* a, const float* b, float* out, int Hs, int Ws, long planes, hipStream_t s) {
     const long total = planes * Hs * ((Ws + 1) / 2);
     long blocks = std::min<long>(cdivl(total, 256), 8192);
@@ -1543,10 +1599,19 @@ static bool pred_fusable(const bde_model* m) { return m->cfg.basechannels <= 64 
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
                        hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr) {
     const PackedLayer& pl = m->dec[j];
-    { ProfScope ps(m, pname("dec_up", j), s); BDE_TRY(upsample2x_sum(in, skip, m->W().up, Hs, Ws, (long)N * pl.Cin, s)); }
+    Workspace& ws = m->W();
+    // a split-bf16 convolution reads SB16: the upsampling kernel then writes that image directly (no fp32 map, no conversion)
+    const bool to_sb = m->fuse_enc_sb && !pred_out && conv_takes_sb(m, pl, 1, N, 2 * Hs, 2 * Ws) && ws.sb &&
+                       split_bf16_bytes(N, pl.Cin, 4L * Hs * Ws) <= ws.sb_bytes;
+    {
+        ProfScope ps(m, pname("dec_up", j), s);
+        if (to_sb) BDE_TRY(upsample2x_sum_split(in, skip, ws.sb, N, pl.Cin, Hs, Ws, s));
+        else BDE_TRY(upsample2x_sum(in, skip, ws.up, Hs, Ws, (long)N * pl.Cin, s));
+    }
     ConvCall d;
     d.pl = &pl;
-    d.in = m->W().up;
+    d.in = to_sb ? ws.sb : ws.up;
+    d.in_sb = to_sb;
     d.out = out;
     d.N = N;
     d.Hs = 2 * Hs;

@@ -50,10 +50,10 @@ constexpr int SB_LDS_PITCH = 112;      // + 16 B: sixteen lanes' 16-byte reads l
 
 #ifdef BDE_CONV_TU
 // fp32 [N][C][H][W] -> SB16 [N][C16][H][W][3][16].  grid (ceil(HW / 128), C16, N), 256 threads: thread = (pixel, half of
-// the chunk): 8 plane loads (coalesced along W), three 16-byte stores.
+// the chunk), a wave = 64 consecutive pixels of one half: 8 plane loads of 256 contiguous bytes each, three 16-byte stores.
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, long HW) {
-    const int half = threadIdx.x & 1;
-    const long p = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int half = threadIdx.x >> 7;
+    const long p = (long)blockIdx.x * 128 + (threadIdx.x & 127);
     const int c16 = blockIdx.y;
     const long n = blockIdx.z;
     if (p >= HW) return;

@@ -98,10 +98,11 @@ def test_stride2_encoder_conv(model_a):
         assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), name
 
 
-def test_encoder_epilogue_writes_the_gate_conv_input(model_a):
-    """By default the encoder convolution stores its result only as the SB16 image its gate convolution reads
-    (conv_mfma.h sb_out; fp32 and split-bf16 encoder kernels alike).  The split is the same arithmetic as split_bf16_kernel's,
-    so the frames equal those of the unfused schedule bit for bit."""
+def test_producers_write_the_split_bf16_inputs(model_a):
+    """By default the producer of a split-bf16 convolution's input stores it directly as SB16 (the encoder convolution's
+    epilogue for its gate convolution, conv_mfma.h sb_out; the bilinear x2 of decoders 0 and 1, upsample2x_sum_split_kernel):
+    no fp32 map, no conversion pass.  Same split arithmetic as split_bf16_kernel, so the frames agree with the unfused
+    schedule to rounding of the bilinear expression (its fused-multiply-add contraction may differ between the two kernels)."""
     from tests.util import golden_inputs
     cfg, sd, m = model_a
     xs = golden_inputs(6, 1, 5, 184, 240, 1234)
@@ -113,7 +114,7 @@ def test_encoder_epilogue_writes_the_gate_conv_input(model_a):
     finally:
         m.set_tuning('fuse_enc_sb', 1)
     assert torch.isfinite(y1).all()
-    assert torch.equal(y0, y1)
+    assert maxabs(y0, y1) <= 2e-6
 
 
 def test_gate_conv_random_shapes(model_a):
