@@ -567,6 +567,7 @@ struct bde_model {
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
+    int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
     int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
     int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
@@ -933,6 +934,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.res1_gs = a.res2_gs = cc.out_gs;
     a.w_gs = pl.w_sz;
     a.bias_gs = pl.Cout;
+    a.xcd_remap = m->xcd_remap;
     if (cc.out_sb) {
         a.sb_out = reinterpret_cast<unsigned short*>(cc.out_sb);
         a.sb_out_ns = (long)cdiv(pl.Cout, 16) * a.Ho * a.Wo * 48;
@@ -1998,6 +2000,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     }
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_sb") {
         if (m->lstm_sb_mode != (int)value)
             for (auto& w : m->wslots) w.release();

@@ -76,6 +76,7 @@ struct ConvArgs {
     // (conv_sb.h: the input layout of the convolution that consumes it), not as fp32 planes; Cout % 32 == 0, no residuals
     unsigned short* sb_out;
     long sb_out_gs, sb_out_ns;   // group / frame strides in bf16 elements
+    int xcd_remap;               // conv_sb.h: workgroup order that keeps neighbouring tiles in one XCD's L2
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU
@@ -118,6 +119,24 @@ __device__ __forceinline__ void sb_split3_dev(float x, unsigned short& hi, unsig
     mid = sb_rne_dev(r1);
     const float r2 = r1 - __builtin_bit_cast(float, (unsigned)mid << 16);
     lo = sb_rne_dev(r2);
+}
+// Workgroup -> (pixel tile bx, channel group by, frame z) of the batched convolutions.  The dispatcher deals consecutive
+// workgroups round-robin to the 8 XCDs, each with an L2 of its own: in the plain (x fastest) order the row tiles above and
+// below a tile -- most of its halo -- and the other channel groups of its pixels live in seven other L2s.  With `remap`
+// every XCD gets one contiguous range of the (frame, pixel tile, channel group) order instead, channel group fastest.
+__device__ __forceinline__ void conv_block_coords(int remap, int& bx, int& by, int& z) {
+    bx = blockIdx.x; by = blockIdx.y; z = blockIdx.z;
+    if (remap) {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned total = gx * gy * gridDim.z;
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
+        const unsigned L = xcd * q + min(xcd, rem) + (lin >> 3);
+        by = (int)(L % gy);
+        const unsigned r = L / gy;
+        bx = (int)(r % gx);
+        z = (int)(r / gx);
+    }
 }
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -164,16 +164,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int hl = lane >> 5;
-    const int z = blockIdx.z;
+    int bx, by, z;
+    conv_block_coords(a.xcd_remap, bx, by, z);
     const int g = z / a.N, n = z - g * a.N;
     const int HW = a.Ho * a.Wo;
     int p0, p_end;
     if (a.row_tiles > 0) {
-        const int yy = blockIdx.x / a.row_tiles, xt = blockIdx.x - yy * a.row_tiles;
+        const int yy = bx / a.row_tiles, xt = bx - yy * a.row_tiles;
         p0 = yy * a.Wo + xt * BN;
         p_end = min(p0 + BN, (yy + 1) * a.Wo);
     } else {
-        p0 = blockIdx.x * BN;
+        p0 = bx * BN;
         p_end = min(p0 + BN, HW);
     }
     const int p_last = p_end - 1;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
         }
     };
     // weight fragments: [co tile][chunk][tap][term][64][8] bf16
-    const int cot0 = (blockIdx.y * WM + wm) * MT;
+    const int cot0 = (by * WM + wm) * MT;
     const int ncot = (a.Cout + 31) / 32;
     const sb8* wfr[MT];
 #pragma unroll

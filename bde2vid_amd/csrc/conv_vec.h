@@ -51,16 +51,17 @@ __global__ __launch_bounds__(256) void conv_vec_kernel(const ConvArgs a) {
     float* const lds = lds_all + ASZ;                 // halo tile [CK][R][IW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int z = blockIdx.z;
+    int bx, by, z;
+    conv_block_coords(a.xcd_remap, bx, by, z);
     const int g = z / a.N, n = z - g * a.N;
     const int HW = a.Ho * a.Wo;
     int p0, p_end;
     if (a.row_tiles > 0) {
-        const int yy = blockIdx.x / a.row_tiles, xt = blockIdx.x - yy * a.row_tiles;
+        const int yy = bx / a.row_tiles, xt = bx - yy * a.row_tiles;
         p0 = yy * a.Wo + xt * BN;
         p_end = min(p0 + BN, (yy + 1) * a.Wo);
     } else {
-        p0 = blockIdx.x * BN;
+        p0 = bx * BN;
         p_end = min(p0 + BN, HW);
     }
     const int p_last = p_end - 1;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_vec_kernel(const ConvArgs a) {
         for (int k = 0; k < AK4; ++k) {
             const int i4 = min(tid + k * 256, ASZ / 4 - 1);
             const int m = i4 / (FRAG / 4), r4 = i4 - m * (FRAG / 4);
-            aw[k] = reinterpret_cast<const cvf4*>(wg + ((long)(blockIdx.y * MT + m) * a.nchunks + st) * FRAG)[r4];
+            aw[k] = reinterpret_cast<const cvf4*>(wg + ((long)(by * MT + m) * a.nchunks + st) * FRAG)[r4];
         }
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_vec_kernel(const ConvArgs a) {
     float mu[NT], rstd[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) mu[t] = rstd[t] = 0.f;
-    generic_epilogue<MT, NT, 16>(a, fin, pix, 0, lane, g, n, HW, p_end, false, mu, rstd);
+    generic_epilogue<MT, NT, 16>(a, fin, pix, 0, lane, g, n, HW, p_end, false, mu, rstd, by * MT);
 }
 
 constexpr int CV_MAXI4 = 3;    // max float4 staging slots per thread and channel (1, 2 or 3 are built)

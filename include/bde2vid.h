@@ -106,6 +106,8 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *                      attention block as one fused kernel instead of three GEMM launches (default 160).
  *   "conv_sb": 1 (default) runs the batched convolutions that have a split-bf16 shape (csrc/conv_sb.h) on the bf16
  *              matrix cores with three-term split operands (fp32-equivalent); 0 keeps every convolution on the fp32 kernels.
+ *   "xcd_remap": 1 (default) orders the workgroups of the batched convolutions so that each XCD's L2 sees one contiguous
+ *              range of (frame, pixel tile, channel group); 0 = plain grid order.  Same results.
  *   "fuse_enc_sb": 1 (default) lets an encoder convolution store its result only as the split-bf16 image its gate
  *              convolution reads; 0 writes fp32 planes and converts them in a pass of their own (same frames, bit for bit).
  *   "winblock": 1 (default) runs an attention block of a 64-channel / 16-head level as ONE launch
