@@ -129,10 +129,19 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict
                                                           long n_single, int nb, int H, int W, int TH, int TW, int ntw,
                                                           float* __restrict__ grids, int* __restrict__ oob) {
     extern __shared__ float tile[];                    // [nb][TH][TW]
-    const int seg = blockIdx.y;
+    // The tiles of a window stream the same events: they go to ONE XCD (the dispatcher deals consecutive workgroups round-robin
+    // to the 8 XCDs, so in grid order tile k of every window would land on XCD k and each L2 would pull every event itself).
+    int tix, seg;
+    {
+        const unsigned gx = gridDim.x, total = gx * gridDim.y, lin = blockIdx.x + gx * blockIdx.y;
+        const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
+        const unsigned L = xcd * q + min(xcd, rem) + (lin >> 3);
+        tix = (int)(L % gx);
+        seg = (int)(L / gx);
+    }
     const long beg = starts ? starts[seg] : 0;
     const long end = ends ? ends[seg] : n_single;
-    const int ty0 = ((int)blockIdx.x / ntw) * TH, tx0 = ((int)blockIdx.x % ntw) * TW;
+    const int ty0 = (tix / ntw) * TH, tx0 = (tix % ntw) * TW;
     const int th = min(TH, H - ty0), tw = min(TW, W - tx0);
     const int tpx = TH * TW;
     for (int i = threadIdx.x; i < nb * tpx; i += blockDim.x) tile[i] = 0.f;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict
             if (xi < 0) xi += W;                                       // index_put_ wraps negative indices
             if (yi < 0) yi += H;
             if (xi < 0 || xi >= W || yi < 0 || yi >= H) {              // the reference raises IndexError here
-                n_oob += (blockIdx.x == 0);
+                n_oob += (tix == 0);
                 continue;
             }
             const int lx = (int)xi - tx0, ly = (int)yi - ty0;
