@@ -161,39 +161,91 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict
             dt = ts[end - 1] - t0f;
         }
         int n_oob = 0;
-        for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-            long xi, yi;
-            if (NATIVE) { xi = ((const short*)xs_)[i]; yi = ((const short*)ys_)[i]; }
-            else { xi = (long)((const float*)xs_)[i]; yi = (long)((const float*)ys_)[i]; }   // Tensor.long() truncates
-            if (xi < 0) xi += W;                                       // index_put_ wraps negative indices
-            if (yi < 0) yi += H;
-            if (xi < 0 || xi >= W || yi < 0 || yi >= H) {              // the reference raises IndexError here
-                n_oob += (tix == 0);
-                continue;
-            }
-            const int lx = (int)xi - tx0, ly = (int)yi - ty0;
-            if (lx < 0 || lx >= tw || ly < 0 || ly >= th) continue;    // another tile's event
-            float tn, p;
-            if (NATIVE) {
-                tn = ((float)(((const double*)ts_)[i] - t0d) - 0.0f) / dt * bm1;
-                p = ((const unsigned char*)ps_)[i] ? 1.0f : -1.0f;
+        // One event = its coordinates tested against the tile, then (one event in ntiles) time stamp, polarity and two LDS
+        // atomics.  A thread takes FOUR consecutive events per iteration, their coordinates as one 8-byte (int16 columns) or
+        // 16-byte (float columns) load each: with one event per iteration the loop was a chain of dependent round trips
+        // (24 M events: 366 iterations x ~1.6 us per workgroup).  The walk starts at beg rounded down to a multiple of four
+        // ; the last group of a window falls back to single loads.
+        // Phase 1 per group: tile test of the four events; phase 2: time stamps and polarities of the accepted ones, fetched by
+        // ALL lanes in one go (a rejected event re-reads the window's first element: a broadcast hit) -- as four branches they
+        // were four more serialized round trips per iteration, since some lane of a wave accepts each of the four.
+        auto load_xy = [&](long i4, long (&xi)[4], long (&yi)[4], bool vec_ok) {
+            if (vec_ok && i4 + 3 < end) {
+                if (NATIVE) {
+                    const short4 xv = *reinterpret_cast<const short4*>((const short*)xs_ + i4);
+                    const short4 yv = *reinterpret_cast<const short4*>((const short*)ys_ + i4);
+                    xi[0] = xv.x; xi[1] = xv.y; xi[2] = xv.z; xi[3] = xv.w;
+                    yi[0] = yv.x; yi[1] = yv.y; yi[2] = yv.z; yi[3] = yv.w;
+                } else {
+                    const float4 xv = *reinterpret_cast<const float4*>((const float*)xs_ + i4);
+                    const float4 yv = *reinterpret_cast<const float4*>((const float*)ys_ + i4);
+                    xi[0] = (long)xv.x; xi[1] = (long)xv.y; xi[2] = (long)xv.z; xi[3] = (long)xv.w;   // Tensor.long() truncates
+                    yi[0] = (long)yv.x; yi[1] = (long)yv.y; yi[2] = (long)yv.z; yi[3] = (long)yv.w;
+                }
             } else {
-                tn = (((const float*)ts_)[i] - t0f) / dt * bm1;        // :490 (division, then multiply, fp32)
-                p = ((const float*)ps_)[i];
-            }
-            float* cell = tile + ly * TW + lx;
-            if (!(tn == tn)) {                                         // dt == 0 -> NaN weights in every bin (:494-495)
-                for (int b = 0; b < nb; ++b) atomicAdd(cell + b * tpx, p * tn);
-                continue;
-            }
-            const int b0 = (int)floorf(tn);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int b = b0 + k;
-                if (b < 0 || b >= nb) continue;
-                const float w = fmaxf(0.f, 1.0f - fabsf(tn - (float)b));   // :494
-                const float v = p * w;                                      // :495
-                if (v != 0.f) atomicAdd(cell + b * tpx, v);
+                for (int u = 0; u < 4; ++u) {
+                    const long i = max(min(i4 + u, end - 1), beg);
+                    if (NATIVE) { xi[u] = ((const short*)xs_)[i]; yi[u] = ((const short*)ys_)[i]; }
+                    else { xi[u] = (long)((const float*)xs_)[i]; yi[u] = (long)((const float*)ys_)[i]; }
+                }
+            }
+        };
+        // (a column handed over as a view with an odd storage offset takes the single loads throughout)
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(xs_) | reinterpret_cast<uintptr_t>(ys_)) & (NATIVE ? 7u : 15u)) == 0;
+        const long stride = 4L * blockDim.x;
+        long i4 = (beg & ~3L) + 4L * threadIdx.x;
+        long xn[4], yn[4];
+        if (i4 < end) load_xy(i4, xn, yn, vec_ok);
+        for (; i4 < end; i4 += stride) {
+            long xi[4], yi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { xi[u] = xn[u]; yi[u] = yn[u]; }
+            if (i4 + stride < end) load_xy(i4 + stride, xn, yn, vec_ok);        // next group in flight during this one
+            bool take[4];
+            int cellofs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                long x = xi[u], y = yi[u];
+                const bool mine = i4 + u >= beg && i4 + u < end;
+                if (x < 0) x += W;                                     // index_put_ wraps negative indices
+                if (y < 0) y += H;
+                const bool inside = x >= 0 && x < W && y >= 0 && y < H;
+                if (mine && !inside) n_oob += (tix == 0);              // the reference raises IndexError here
+                const int lx = (int)x - tx0, ly = (int)y - ty0;
+                take[u] = mine && inside && lx >= 0 && lx < tw && ly >= 0 && ly < th;   // else another tile's event
+                cellofs[u] = ly * TW + lx;
+            }
+            float tn[4], pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = take[u] ? i4 + u : beg;
+                if (NATIVE) {
+                    tn[u] = ((float)(((const double*)ts_)[i] - t0d) - 0.0f) / dt * bm1;
+                    pp[u] = ((const unsigned char*)ps_)[i] ? 1.0f : -1.0f;
+                } else {
+                    tn[u] = (((const float*)ts_)[i] - t0f) / dt * bm1;  // :490 (division, then multiply, fp32)
+                    pp[u] = ((const float*)ps_)[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!take[u]) continue;
+                float* cell = tile + cellofs[u];
+                const float t = tn[u], p = pp[u];
+                if (!(t == t)) {                                       // dt == 0 -> NaN weights in every bin (:494-495)
+                    for (int b = 0; b < nb; ++b) atomicAdd(cell + b * tpx, p * t);
+                    continue;
+                }
+                const int b0 = (int)floorf(t);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int b = b0 + k;
+                    if (b < 0 || b >= nb) continue;
+                    const float w = fmaxf(0.f, 1.0f - fabsf(t - (float)b));    // :494
+                    const float v = p * w;                                      // :495
+                    if (v != 0.f) atomicAdd(cell + b * tpx, v);
+                }
             }
         }
         if (oob && n_oob) atomicAdd(oob, n_oob);
