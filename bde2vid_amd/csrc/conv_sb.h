@@ -337,7 +337,7 @@ static inline long conv_sb_halo_pixels(int KS, int STRIDE, int BN, int Win, int 
 
 // Workgroup shapes (output channels x pixels; all four waves):
 //   SB_128x128  four waves of 32 x 128 sharing the pixel fragments (the 3x3 gate convolutions, decoder 0)
-//   SB_128x64   four waves of 32 x 64: maps narrower than 128 pixels / stride-2 halos that do not fit at 128 (5x5 only)
+//   SB_128x64   four waves of 32 x 64: rows that 128-pixel tiles fill badly / stride-2 halos that do not fit at 128
 //   SB_64x128   2 x 2 waves of 32 x 64 for 64 output channels (5x5 stride 1: decoder 1)
 enum { SB_NONE = 0, SB_128x128, SB_128x64, SB_64x128 };
 // pixel tiles aligned to image rows when a row is at least 3/4 of a tile (row_tiles > 0), linear over rows otherwise
@@ -347,19 +347,36 @@ static inline int conv_sb_row_tiles(int BN, int Ho, int Wo) {
     const double fill_row = (double)Wo / ((double)rt * BN);
     return fill_row >= fill_lin - 0.1 ? rt : 0;
 }
-static inline bool conv_sb_tile_fits(int KS, int stride, int BN, int Win, int Ho, int Wo) {
-    const long halo = conv_sb_halo_pixels(KS, stride, BN, Win, Ho, Wo, conv_sb_row_tiles(BN, Ho, Wo));
-    return halo * SB_LDS_PITCH <= 78 * 1024 && (halo * 7 + 63) / 64 <= 4 * 24;       // two workgroups per CU; <= 24 DMA blocks per wave
+// How the pixel tiles of BN pixels are laid over the map: row_tiles > 0 (aligned to image rows), 0 (linear over rows), or
+// -1 when the halo fits LDS neither way (two workgroups per CU, <= 24 DMA blocks per wave).  The fuller layout is tried
+// first; a 320-pixel row does not take linear 128-pixel tiles (a tile across two rows stages four full rows) but does take
+// 128 + 128 + 64.
+static inline int conv_sb_tile_mode(int KS, int stride, int BN, int Win, int Ho, int Wo) {
+    auto fits = [&](int rt) {
+        const long halo = conv_sb_halo_pixels(KS, stride, BN, Win, Ho, Wo, rt);
+        return halo * SB_LDS_PITCH <= 78 * 1024 && (halo * 7 + 63) / 64 <= 4 * 24;
+    };
+    const int pref = conv_sb_row_tiles(BN, Ho, Wo);
+    if (fits(pref)) return pref;
+    const int other = pref ? 0 : cdiv(Wo, BN);
+    return fits(other) ? other : -1;
 }
-// Which shape conv_sb_launch takes for this convolution (asked before the input is split)
+static inline double conv_sb_fill(int BN, int Ho, int Wo, int rt) {
+    return rt > 0 ? (double)Wo / ((double)rt * BN) : (double)Ho * Wo / ((double)cdiv(Ho * Wo, BN) * BN);
+}
+// Which shape conv_sb_launch takes for this convolution (asked before the input is split).  Among the pixel-tile widths
+// that fit, the better filled one; 128 pixels reuse every weight fragment twice as often as 64, so 64 has to be 15 % fuller.
 static inline int conv_sb_pick(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
     if (!((KS == 3 && stride == 1) || (KS == 5 && (stride == 1 || stride == 2)))) return SB_NONE;
+    const int m128 = conv_sb_tile_mode(KS, stride, 128, Win, Ho, Wo);
+    const double f128 = m128 >= 0 ? conv_sb_fill(128, Ho, Wo, m128) : 0.0;
     if (Cout >= 128) {
-        if (conv_sb_tile_fits(KS, stride, 128, Win, Ho, Wo)) return SB_128x128;
-        if (KS == 5 && conv_sb_tile_fits(KS, stride, 64, Win, Ho, Wo)) return SB_128x64;
-        return SB_NONE;
+        const int m64 = conv_sb_tile_mode(KS, stride, 64, Win, Ho, Wo);
+        const double f64 = m64 >= 0 ? 0.85 * conv_sb_fill(64, Ho, Wo, m64) : 0.0;
+        if (f128 < 0.6 && f64 < 0.6 * 0.85) return SB_NONE;
+        return f128 >= f64 ? SB_128x128 : SB_128x64;
     }
-    if (Cout == 64 && KS == 5 && stride == 1 && conv_sb_tile_fits(KS, stride, 128, Win, Ho, Wo)) return SB_64x128;
+    if (Cout == 64 && KS == 5 && stride == 1 && f128 >= 0.6) return SB_64x128;
     return SB_NONE;
 }
 static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
@@ -386,7 +403,8 @@ template <int KS, int STRIDE, int MT, int NT, int WM, int WN>
 static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* launched) {
     constexpr int BN = WN * NT * 32;
     *launched = false;
-    const int best_rt = conv_sb_row_tiles(BN, a.Ho, a.Wo);
+    const int best_rt = conv_sb_tile_mode(KS, STRIDE, BN, a.Win, a.Ho, a.Wo);
+    if (best_rt < 0) return BDE_OK;
     a.row_tiles = best_rt;
     const long halo = conv_sb_halo_pixels(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, best_rt);
     const long blocks = (halo * 7 + 63) / 64;                               // 1-KiB DMA blocks of the tile
@@ -414,11 +432,9 @@ static int conv_sb_launch_ks(const ConvArgs& a, int G, hipStream_t stream, bool*
         if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2>(a, G, stream, launched);
         return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1>(a, G, stream, launched);
     }
-    if constexpr (KS == 5) {
-        if (shape == SB_128x64) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 4, 1>(a, G, stream, launched);
-        if constexpr (STRIDE == 1)
-            if (shape == SB_64x128) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 2, 2>(a, G, stream, launched);
-    }
+    if (shape == SB_128x64) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 4, 1>(a, G, stream, launched);
+    if constexpr (KS == 5 && STRIDE == 1)
+        if (shape == SB_64x128) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 2, 2>(a, G, stream, launched);
     *launched = false;
     return BDE_OK;
 }
