@@ -163,9 +163,9 @@ KERNEL_OF_SPAN = [
     (r'lstm(\d)', r'lstm16_step_kernel', 'recurrent ConvLSTM step of level {0}, both directions (csrc/lstm16.h)'),
     (r'winblock(\d)', r'winblock_kernel', 'one temporal window-attention block of level {0} per launch (csrc/winblock.h)'),
     (r'wideblock(\d)', r'wideblock_', 'temporal window-attention block of level {0} (csrc/wideblock.h)'),
-    (r'gates_x(\d)', r'conv_vec_kernel<3, 1', 'x-part of the ConvLSTM gates of level {0}, 3x3 conv batched over T, both directions (csrc/conv_vec.h)'),
-    (r'enc_conv(\d)', r'conv_vec_kernel<5, 2', 'encoder 5x5 stride-2 conv of level {0}, batched over T, both directions (csrc/conv_vec.h)'),
-    (r'dec_conv(\d)', r'conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_vec.h)'),
+    (r'gates_x(\d)', r'conv_sb_kernel<3, 1|conv_vec_kernel<3, 1', 'x-part of the ConvLSTM gates of level {0}, 3x3 conv batched over T, both directions (csrc/conv_sb.h; conv_vec.h when no split-bf16 shape fits)'),
+    (r'enc_conv(\d)', r'conv_sb_kernel<5, 2|conv_vec_kernel<5, 2', 'encoder 5x5 stride-2 conv of level {0}, batched over T, both directions (csrc/conv_sb.h / conv_vec.h)'),
+    (r'dec_conv(\d)', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_sb.h / conv_vec.h)'),
     (r'head', r'conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_vec.h)'),
     (r'chain_(\w+?)(\d)', r'pw_gemm_kernel|attn_mfma16_kernel|attn_core_kernel|token_fused_kernel', 'split attention path of level {1}: {0}'),
     (r'wide_core(\d)', r'attn_tok16_kernel', 'window-attention core of level {0}, one workgroup per (window, head) (csrc/wideblock.h)'),
