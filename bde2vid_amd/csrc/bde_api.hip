@@ -2066,6 +2066,14 @@ int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n) {
     return BDE_OK;
 }
 
+int bde_debug_conv_shape(int32_t ks, int32_t stride, int32_t cout, int32_t in_h, int32_t in_w, int32_t* row_tiles) {
+    const int pad = ks / 2;
+    const int Ho = (in_h + 2 * pad - ks) / stride + 1, Wo = (in_w + 2 * pad - ks) / stride + 1;
+    const int shape = conv_sb_pick(ks, stride, cout, in_w, Ho, Wo);
+    if (row_tiles) *row_tiles = shape == SB_NONE ? 0 : conv_sb_tile_mode(ks, stride, shape == SB_128x64 ? 64 : 128, in_w, Ho, Wo);
+    return shape;
+}
+
 int bde_debug_occupancy(const char* kernel) {
     int nb = -1;
     std::string k(kernel ? kernel : "");

@@ -215,3 +215,34 @@ def test_checkpoint_with_code_payload_is_rejected(tmp_path):
     good = tmp_path / 'good.pth'
     torch.save({'state_dict': {'a': torch.ones(2)}, 'meta': {'cfg': 'model = dict()'}}, str(good))
     assert torch.equal(read_checkpoint(str(good))['state_dict']['a'], torch.ones(2))
+
+
+def test_split_bf16_conv_shapes_at_the_baseline_resolutions():
+    """Host arithmetic of csrc/conv_sb.h (conv_sb_pick / conv_sb_tile_mode), no GPU: which workgroup shape and pixel-tile
+    layout each batched convolution of the canonical config takes at the BASELINE resolutions (0 = fp32 kernels,
+    1 = 128 channels x 128 pixels, 2 = 128 x 64, 3 = 64 x 128; second number = tiles per image row, 0 = linear)."""
+    import ctypes as C
+    from bde2vid_amd import _lib
+    L = _lib.lib()
+
+    def shape(ks, stride, cout, h, w):
+        rt = C.c_int32(-9)
+        return L.bde_debug_conv_shape(ks, stride, cout, h, w, C.byref(rt)), rt.value
+
+    expect = {
+        (184, 240): dict(enc=[(0, 0), (2, 1), (2, 0)], gx=[(1, 1), (1, 0), (1, 0)], dec=[(1, 0), (3, 1), (0, 0)]),
+        (264, 352): dict(enc=[(0, 0), (2, 2), (2, 1)], gx=[(1, 0), (1, 0), (1, 0)], dec=[(1, 0), (3, 2), (0, 0)]),
+        (480, 640): dict(enc=[(0, 0), (2, 3), (2, 2)], gx=[(2, 5), (1, 0), (1, 0)], dec=[(2, 3), (3, 3), (0, 0)]),
+        (720, 1280): dict(enc=[(0, 0), (2, 5), (2, 3)], gx=[(1, 5), (2, 5), (1, 0)], dec=[(2, 5), (3, 5), (0, 0)]),
+    }
+    chans = (64, 128, 256)
+    for (H, W), e in expect.items():
+        for l, cout in enumerate(chans):
+            hin, win = H >> l, W >> l
+            assert shape(5, 2, cout, hin, win) == e['enc'][l], ('enc', H, W, l)
+            assert shape(3, 1, 4 * cout, hin // 2, win // 2) == e['gx'][l], ('gx', H, W, l)
+        for j, cout in enumerate((128, 64, 32)):
+            l = 2 - j
+            assert shape(5, 1, cout, (H >> (l + 1)) * 2, (W >> (l + 1)) * 2) == e['dec'][j], ('dec', H, W, j)
+    # not a convolution the split-bf16 kernels are built for
+    assert shape(7, 1, 128, 64, 64)[0] == 0 and shape(3, 2, 128, 64, 64)[0] == 0
