@@ -117,6 +117,27 @@ def test_producers_write_the_split_bf16_inputs(model_a):
     assert maxabs(y0, y1) <= 2e-6
 
 
+def test_workgroup_order_does_not_change_results_and_info_keys(model_a):
+    """xcd_remap only permutes which workgroup computes which tile: frames are bit-identical with it on and off; get_info
+    reports which convolutions of the latest forward ran as split bf16 (config A at 184 x 240: everything but the level-0
+    encoder and the last decoder, whose epilogue carries predI)."""
+    from tests.util import golden_inputs
+    cfg, sd, m = model_a
+    xs = golden_inputs(16, 1, 5, 184, 240, 4321)
+    inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    try:                                  # (16 frames: every level is over the launch-size threshold of the split-bf16 kernels)
+        y1 = torch.stack(m(inp))
+        took = {k: m.get_info(k) for k in ('sb_enc0', 'sb_enc1', 'sb_enc2', 'sb_gx0', 'sb_gx1', 'sb_gx2', 'sb_dec0', 'sb_dec1', 'sb_dec2')}
+        m.set_tuning('xcd_remap', 0)
+        y0 = torch.stack(m(inp))
+    finally:
+        m.set_tuning('xcd_remap', 1)
+    assert took == dict(sb_enc0=0, sb_enc1=1, sb_enc2=1, sb_gx0=1, sb_gx1=1, sb_gx2=1, sb_dec0=1, sb_dec1=1, sb_dec2=0), took
+    assert torch.equal(y0, y1)
+    with pytest.raises(Exception):
+        m.get_info('sb_enc9')
+
+
 def test_gate_conv_random_shapes(model_a):
     """Seeded sweep: odd widths (tiles straddling rows), maps narrower / wider than a pixel tile, few and many frames, on
     both sides of the launch-size threshold under which the fp32 kernels are used."""
