@@ -195,10 +195,7 @@ static inline int attn_launch(AttnArgs a, int B, hipStream_t stream) {
         auto kern = attn_core_kernel<HDV>;                                                            \
         if (lds > 64 * 1024) {                                                                        \
             static unsigned char raised[BDE_MAX_DEVICES];                                                               \
-            if (first_use_on_device(raised)) {                                                                            \
-                BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            160 * 1024));                                             \
-            }                                                                                         \
+            BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));                                    \
         }                                                                                             \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                        \
         break;                                                                                        \

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -610,8 +611,10 @@ struct ProfScope {
 // span names with an index ("lstm0", "dec_conv2"): interned, the spans keep the pointer
 static const char* pname(const char* base, int i) {
     static std::map<std::string, std::string> names;
+    static std::mutex mu;                               // forwards of two models may run on two host threads
     const std::string k = std::string(base) + std::to_string(i);
-    return names.emplace(k, k).first->second.c_str();
+    std::lock_guard<std::mutex> lock(mu);
+    return names.emplace(k, k).first->second.c_str();   // (map nodes never move: the pointer stays valid)
 }
 
 static const std::string GP = "generator.";
@@ -2200,12 +2203,13 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
                                oob_count, (hipStream_t)stream);
 }
 
-int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, const int64_t* starts,
-                              const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H, int32_t W, float* grids,
-                              int32_t* oob_count, void* stream) {
-    BDE_REQUIRE(grids && starts && ends && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
+int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, int64_t n_events,
+                              const int64_t* starts, const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H, int32_t W,
+                              float* grids, int32_t* oob_count, void* stream) {
+    BDE_REQUIRE(grids && starts && ends && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1 && n_events >= 0, "bad argument");
+    BDE_REQUIRE(n_events == 0 || (xs && ys && ts && ps), "null event column");
     return voxel_tile_launch<true>(xs, ys, ts, ps, (const long*)starts, (const long*)ends, 0, nwin, num_bins, H, W, grids, oob_count,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, (long)n_events);
 }
 
 int bde_find_ts_index(const double* ts, int64_t n, const double* timestamps, int32_t nq, int64_t* out, void* stream) {

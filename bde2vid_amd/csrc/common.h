@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/bde2vid.h"   // status codes
@@ -58,14 +59,23 @@ struct TuningScope {
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: remember per device (not per
-// process) that it has been raised.  `seen` is one static array per kernel instantiation.
+// process) that it has been raised.  `seen` is one static array per kernel instantiation.  Safe against concurrent
+// forwards from several host threads: the flag is published (release) only after the attribute is set, and the slow
+// path is serialised.
 constexpr int BDE_MAX_DEVICES = 64;
-inline bool first_use_on_device(unsigned char (&seen)[BDE_MAX_DEVICES]) {
+inline std::mutex& lds_attr_mutex() {
+    static std::mutex mu;
+    return mu;
+}
+inline hipError_t raise_dynamic_lds(unsigned char (&seen)[BDE_MAX_DEVICES], const void* kernel, int bytes = 160 * 1024) {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BDE_MAX_DEVICES) return true;
-    if (seen[d]) return false;
-    seen[d] = 1;
-    return true;
+    const bool indexed = hipGetDevice(&d) == hipSuccess && d >= 0 && d < BDE_MAX_DEVICES;
+    if (indexed && __atomic_load_n(&seen[d], __ATOMIC_ACQUIRE)) return hipSuccess;
+    std::lock_guard<std::mutex> lock(lds_attr_mutex());
+    if (indexed && __atomic_load_n(&seen[d], __ATOMIC_ACQUIRE)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && indexed) __atomic_store_n(&seen[d], (unsigned char)1, __ATOMIC_RELEASE);
+    return e;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -98,8 +98,10 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    // compare + select, not fmaxf / fminf: those return the non-NaN operand, and torch's ReLU / ReLU6 hand a NaN on
+    // (a voxel grid of a zero-duration event window is NaN, event_utils.py:489-495: the reference's frames then are too)
+    if (act == ACT_RELU) return v < 0.f ? 0.f : v;
+    if (act == ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
     if (act == ACT_GELU) return gelu_f(v);
     return v;
 }
@@ -115,6 +117,7 @@ __device__ __forceinline__ unsigned short sb_rne_dev(float x) {
 }
 __device__ __forceinline__ void sb_split3_dev(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
     hi = sb_rne_dev(x);
+    if ((__builtin_bit_cast(unsigned, x) & 0x7f800000u) == 0x7f800000u) { mid = lo = 0; return; }   // Inf / NaN ride in the leading term alone
     const float r1 = x - __builtin_bit_cast(float, (unsigned)hi << 16);
     mid = sb_rne_dev(r1);
     const float r2 = r1 - __builtin_bit_cast(float, (unsigned)mid << 16);
@@ -613,9 +616,7 @@ static int conv_launch_t(const ConvArgs& a, int G, hipStream_t stream) {
     auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, CK, SPLITK, EPI, MAXI>;
     if (lds > 64 * 1024) {
         static unsigned char raised[BDE_MAX_DEVICES];
-        if (first_use_on_device(raised)) {
-            BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+        BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
     }
     constexpr int BN = (SPLITK ? 1 : 4) * NT * 32;
     const int co_rows = (EPI == EPI_LSTM) ? a.Cout / 4 : a.Cout;          // LSTM: 32 hidden ch per block

@@ -36,9 +36,12 @@ __host__ __device__ __forceinline__ unsigned short sb_bf16_rne(float x) {
     return (unsigned short)(u >> 16);
 }
 __host__ __device__ __forceinline__ float sb_bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
-// x = hi + mid + lo with three bf16 terms (exact for every finite fp32 x whose low term does not underflow)
+// x = hi + mid + lo with three bf16 terms (exact for every finite fp32 x whose low term does not underflow; a finite x
+// that rounds up to an infinite bf16 -- |x| > 3.39e38 -- keeps hi = Inf with mid = -Inf: out of range for this scheme)
 __host__ __device__ __forceinline__ void sb_split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
     hi = sb_bf16_rne(x);
+    // Inf / NaN ride in the leading term alone (Inf - Inf would put a NaN into the second term of an infinite value)
+    if ((__builtin_bit_cast(unsigned, x) & 0x7f800000u) == 0x7f800000u) { mid = lo = 0; return; }
     const float r1 = x - sb_bf16_to_f32(hi);
     mid = sb_bf16_rne(r1);
     const float r2 = r1 - sb_bf16_to_f32(mid);
@@ -257,23 +260,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     static_assert(TAPS % RING == 0, "ring position of a tap must not depend on the chunk");
     const int S = C16 * TAPS;                               // (chunk, tap) pairs of the launch
     sb8 af[RING][MT][3];
+    if (DB) stage(0);                                       // BEFORE the fragment prefetch: the counted wait below relies on the DMA being older
 #pragma unroll
     for (int q = 0; q < PF; ++q)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int k = 0; k < 3; ++k) af[q][m][k] = wfr[m][((long)min(q, S - 1) * 3 + k) * 64];
-    if (DB) stage(0);
     for (int c16 = 0; c16 < C16; ++c16) {
         if (!DB) {
             __syncthreads();                               // every wave is done with the previous chunk's tile
             stage(c16);
         }
         const unsigned char* tile = sb_lds + (DB ? (c16 & 1) * tile_bytes : 0);
-        // this wave's DMA blocks have landed; with DB they are older than the PF taps of fragments still in flight
-        if (DB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PF * MT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (DB) {
+            // This wave's DMA blocks of chunk c16 have landed: they were issued before the PF taps of weight fragments that
+            // are still in flight (stage(0) ahead of the prefetch above, stage(c16) ahead of the tap loop of chunk c16 - 1),
+            // so the counted wait covers them and leaves the fragment ring in flight.  A bare s_barrier follows
+            // (__syncthreads() would drain vmcnt to 0 and the ring with it); LDS reads of the other buffer were waited
+            // for by the MFMAs that consumed them.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PF * MT) : "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         if (DB && c16 + 1 < C16) stage(c16 + 1);            // (every wave left the other buffer before that barrier)
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -390,8 +401,7 @@ static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long h
     const size_t lds = (DB ? 2 : 1) * (((size_t)halo_px * 7 + 63) / 64 * 1024);   // whole 1-KiB DMA blocks (7 slots per pixel)
     auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI, DB>;
     static unsigned char raised[BDE_MAX_DEVICES];
-    if (lds > 64 * 1024 && first_use_on_device(raised))
-        BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds > 64 * 1024) BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
     dim3 grid(a.row_tiles > 0 ? a.Ho * a.row_tiles : cdiv(a.Ho * a.Wo, BN), cdiv(a.Cout, WM * MT * 32), G * a.N);
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, a);

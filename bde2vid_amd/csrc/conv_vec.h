@@ -199,9 +199,7 @@ static int conv_vec_launch_i(const ConvArgs& a, int G, hipStream_t stream, long 
     auto kern = conv_vec_kernel<KS, STRIDE, MT, NT, CK, MAXI4>;
     if (lds > 64 * 1024) {
         static unsigned char raised[BDE_MAX_DEVICES];
-        if (first_use_on_device(raised)) {
-            BDE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
+        BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
     }
     constexpr int BN = 4 * NT * 32;
     dim3 grid(a.row_tiles > 0 ? a.Ho * a.row_tiles : cdiv(a.Ho * a.Wo, BN), cdiv(a.Cout, MT * 32), G * a.N);

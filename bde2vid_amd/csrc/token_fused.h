@@ -348,10 +348,7 @@ static int token_launch_t(const TokenArgs& a, int B, hipStream_t stream) {
     const size_t lds = token_lds_bytes(a.C, NPT);
     if (lds > 64 * 1024) {
         static unsigned char raised[BDE_MAX_DEVICES];
-        if (first_use_on_device(raised)) {
-            BDE_HIP(hipFuncSetAttribute((const void*)token_fused_kernel<NPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024));
-        }
+        BDE_HIP(raise_dynamic_lds(raised, (const void*)token_fused_kernel<NPT>));
     }
     dim3 grid(cdiv(a.HW, 16 * NPT), B);
     hipLaunchKernelGGL(token_fused_kernel<NPT>, grid, dim3(256), lds, stream, a);

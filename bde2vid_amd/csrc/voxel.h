@@ -1,17 +1,22 @@
-// Event -> voxel-grid binning as an atomic scatter.
+// Event -> voxel-grid binning.
 //
 // Restates events_to_voxel_torch (events_contrast_maximization/utils/event_utils.py:466-509) and the
 // nearest-pixel branch of events_to_image_torch (:360,371-375).  The reference makes B full passes
 // over the N events (one index_put_(accumulate) per bin); the temporal-bilinear weight
-// max(0, 1-|t_norm-b|) is non-zero for at most two bins, so one pass with two float atomics per
-// event produces the same grid.  Per-event weights are computed with the reference's exact fp32
+// max(0, 1-|t_norm-b|) is non-zero for at most two bins, so one pass with two adds per event
+// produces the same grid.  Per-event weights are computed with the reference's exact fp32
 // expression, so they are bit-identical; only the summation ORDER inside a pixel differs
-// (float atomics), which is why parity for this kernel is 1e-5*max(1,count) instead of bit-exact.
+// (atomic adds), which is why parity for these kernels is 1e-5*max(1,count) instead of bit-exact.
 //
-// HBM/atomic-bound: 16 B read per event + 2 no-return global_atomic_add_f32; the grid is zero-filled
-// in the same call.  MI355X executes float atomics at the memory side (~1.3 TB/s of added bytes,
-// MI355X_MICROARCH.md "Global float atomics"), so no LDS privatisation is attempted: a 5x180x240
-// grid (864 KB) would not fit one CU's LDS anyway.
+// Three kernels, selected by bde_voxel_method:
+//   0  voxel_tile_kernel    (default) a workgroup owns a pixel tile of one window's grid in LDS (all bins), streams the
+//                           window's events and accumulates with LDS atomics; plain coalesced stores, no zero-fill pass.
+//                           Every tile of a window reads the window's events (tiles x 13 B per event, mostly L2 hits).
+//   2  voxel_bucket_*       counting + bucketing pass that moves every event ONCE into the segment of its
+//                           (window, tile); the tile workgroups then read only their own events.  Independent of the
+//                           tile count (480x640: 50 tiles per grid).
+//   1  voxel_scatter_*      one global float atomic per tap: sits on the scattered float-atomic roof of MI355X
+//                           (~0.08 TB/s when the 64 lanes of a wave hit 64 rows); kept for A/B timing.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -126,7 +131,7 @@ template <bool NATIVE>
 __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict__ xs_, const void* __restrict__ ys_,
                                                           const void* __restrict__ ts_, const void* __restrict__ ps_,
                                                           const long* __restrict__ starts, const long* __restrict__ ends,
-                                                          long n_single, int nb, int H, int W, int TH, int TW, int ntw,
+                                                          long n_single, long n_cols, int nb, int H, int W, int TH, int TW, int ntw,
                                                           float* __restrict__ grids, int* __restrict__ oob) {
     extern __shared__ float tile[];                    // [nb][TH][TW]
     // The tiles of a window stream the same events: they go to ONE XCD (the dispatcher deals consecutive workgroups round-robin
@@ -139,8 +144,12 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict
         tix = (int)(L % gx);
         seg = (int)(L / gx);
     }
-    const long beg = starts ? starts[seg] : 0;
-    const long end = ends ? ends[seg] : n_single;
+    long beg = starts ? starts[seg] : 0;
+    long end = ends ? ends[seg] : n_single;
+    if (n_cols >= 0) {                                 // window bounds past the uploaded columns (a file whose attributes
+        beg = min(max(beg, 0L), n_cols);               // disagree with its datasets): clamp, as an h5py slice does
+        end = min(max(end, beg), n_cols);
+    }
     const int ty0 = (tix / ntw) * TH, tx0 = (tix % ntw) * TW;
     const int th = min(TH, H - ty0), tw = min(TW, W - tx0);
     const int tpx = TH * TW;
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void find_ts_index_kernel(const double* __rest
 template <bool NATIVE>
 static inline int voxel_tile_launch(const void* xs, const void* ys, const void* ts, const void* ps, const long* starts,
                                     const long* ends, long n_single, int nseg, int nb, int H, int W, float* grids, int* oob,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, long n_cols = -1) {
     if (oob) BDE_HIP(hipMemsetAsync(oob, 0, sizeof(int), stream));
     if (nseg <= 0) return BDE_OK;
     const long cap = (128 * 1024) / (4L * nb);          // pixels of one tile: all bins in <= 128 KB of LDS
@@ -294,10 +303,14 @@ static inline int voxel_tile_launch(const void* xs, const void* ys, const void* 
     TH = cdiv(H, nth);
     const size_t lds = sizeof(float) * (size_t)nb * TH * TW;
     static unsigned char raised[BDE_MAX_DEVICES];
-    if (first_use_on_device(raised))
-        BDE_HIP(hipFuncSetAttribute((const void*)voxel_tile_kernel<NATIVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(voxel_tile_kernel<NATIVE>, dim3((unsigned)(nth * ntw), (unsigned)nseg), dim3(1024), lds, stream, xs, ys, ts, ps,
-                       starts, ends, n_single, nb, H, W, TH, TW, ntw, grids, oob);
+    BDE_HIP(raise_dynamic_lds(raised, (const void*)voxel_tile_kernel<NATIVE>));
+    // windows ride in grid.y (<= 65535): long recordings go in batches
+    for (int w0 = 0; w0 < nseg; w0 += 65535) {
+        const int nw = std::min(65535, nseg - w0);
+        hipLaunchKernelGGL(voxel_tile_kernel<NATIVE>, dim3((unsigned)(nth * ntw), (unsigned)nw), dim3(1024), lds, stream, xs, ys, ts, ps,
+                           starts ? starts + w0 : nullptr, ends ? ends + w0 : nullptr, n_single, n_cols, nb, H, W, TH, TW, ntw,
+                           grids + (long)w0 * nb * H * W, oob);
+    }
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }

@@ -587,9 +587,7 @@ constexpr size_t winblock_lds_bytes() {
 
 static int winblock_launch(WinArgs a, int B, hipStream_t stream) {
     static unsigned char raised[BDE_MAX_DEVICES];
-    if (first_use_on_device(raised)) {
-        BDE_HIP(hipFuncSetAttribute((const void*)winblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    BDE_HIP(raise_dynamic_lds(raised, (const void*)winblock_kernel));
     a.nWw = a.Wp / 7;
     a.nWin = (a.Hp / 7) * a.nWw;
     a.nA = a.nB = a.nrowsA = a.ncolsB = 0;

@@ -38,6 +38,11 @@ def open_recording(path: str, **kwargs) -> 'Recording':
     return Recording(h5py.File(path, 'r'), **kwargs)
 
 
+class ItemIndexError(IndexError, AssertionError):
+    """An item index outside the recording.  The reference asserts here (h5_dataset.py:210); iteration protocols want an
+    IndexError: this is both."""
+
+
 class Recording:
     def __init__(self, h5_file=None, *, arrays: Optional[dict] = None, sensor_resolution=None, num_bins: int = 5,
                  voxel_method: Optional[dict] = None, max_length: Optional[int] = None, device='cuda'):
@@ -47,6 +52,8 @@ class Recording:
         self.num_bins = num_bins
         self.data_source_idx = -1
         self.frames = None
+        self._frame_names: List[str] = []
+        self._frame_cache: Dict[int, np.ndarray] = {}
         self._event_idx = None
         if (h5_file is None) == (arrays is None):
             raise ValueError('give either an h5py-like file object or arrays=dict(xs, ys, ts, ps, ...)')
@@ -74,8 +81,7 @@ class Recording:
         self.frame_ts = [f['images/{}'.format(n)].attrs['timestamp'] for n in names]
         if names and all('event_idx' in f['images/{}'.format(n)].attrs for n in names):
             self._event_idx = [int(f['images/{}'.format(n)].attrs['event_idx']) for n in names]
-        if names:
-            self.frames = np.stack([np.asarray(f['images/{}'.format(n)][:]) for n in names])
+        self._frame_names = names                  # images are decoded on demand (get_frame), as the reference does (:404-405)
         src = f.attrs.get('source', 'unknown') if hasattr(f.attrs, 'get') else 'unknown'
         self.data_source_idx = DATA_SOURCES.index(src) if src in DATA_SOURCES else -1
         self._upload(cols)
@@ -105,6 +111,10 @@ class Recording:
         n = self.ts.numel()
         if not (self.xs.numel() == self.ys.numel() == self.ps.numel() == n):
             raise ValueError('event columns differ in length')
+        if self.num_events > n:
+            # a file whose num_events attribute overstates its datasets: an h5py slice would stop at the data, and so do we
+            # (event windows are checked against this value, and the binning kernel clamps to the column length as well)
+            self.num_events = n
         ts_h = np.asarray(cols['ts'])
         self.t0 = ts_h[0] if n else 0.0                                      # :429-430 (numpy float64, like the reference)
         self.tk = ts_h[-1] if n else 0.0
@@ -155,30 +165,38 @@ class Recording:
         return out
 
     def set_voxel_method(self, voxel_method: dict):
+        """Select how the event stream is cut into items (:303-317): the item count and the [start, end) table.
+        Counts keep the reference's arithmetic: floor of a float quotient, never negative; `between_frames` has one item
+        fewer than there are images."""
         self.voxel_method = voxel_method
-        m = voxel_method['method']
-        if m == 'k_events':
-            self.length = max(int(self.num_events / (voxel_method['k'] - voxel_method['sliding_window_w'])), 0)
-            self.event_indices = self.compute_k_indices()
-        elif m == 't_seconds':
-            self.length = max(int(self.duration / (voxel_method['t'] - voxel_method['sliding_window_t'])), 0)
-            self.event_indices = self.compute_timeblock_indices()
-        elif m == 'between_frames':
-            self.length = self.num_frames - 1
-            self.event_indices = self.compute_frame_indices()
-        else:
-            raise Exception('Invalid voxel forming method chosen ({})'.format(voxel_method))
+        kind = voxel_method.get('method')
+
+        def strided_count(total, span_key, overlap_key):
+            return max(int(total / (voxel_method[span_key] - voxel_method[overlap_key])), 0)
+        planners = {
+            'k_events': (lambda: strided_count(self.num_events, 'k', 'sliding_window_w'), self.compute_k_indices),
+            't_seconds': (lambda: strided_count(self.duration, 't', 'sliding_window_t'), self.compute_timeblock_indices),
+            'between_frames': (lambda: self.num_frames - 1, self.compute_frame_indices),
+        }
+        if kind not in planners:
+            raise ValueError(f'unknown voxel method {kind!r}: expected one of {sorted(planners)}')
+        count, table = planners[kind]
+        self.length = count()                      # (the index builders iterate over len(self))
+        self.event_indices = table()
         if self.length == 0:
-            raise Exception('Current voxel generation parameters lead to sequence length of zero')
+            raise ValueError(f'voxel method {voxel_method} yields a sequence length of zero items for this recording '
+                             f'({self.num_events} events, {self.num_frames} images, {self.duration} s)')
 
     def __len__(self):
         return self.length
 
     def get_event_indices(self, index):
-        idx0, idx1 = self.event_indices[index]
-        if not (idx0 >= 0 and idx1 <= self.num_events):
-            raise Exception('WARNING: Event indices {},{} out of bounds 0,{}'.format(idx0, idx1, self.num_events))
-        return idx0, idx1
+        """[start, end) of item `index` in the event columns; a window that leaves the recording is an error (:329-334)."""
+        first, last = self.event_indices[index]
+        if first < 0 or last > self.num_events:
+            raise IndexError(f'item {index}: event window [{first}, {last}) is out of bounds for a recording of '
+                             f'{self.num_events} events')
+        return first, last
 
     # ---- items ----------------------------------------------------------------------------------------------------
     def voxels(self, indices: Sequence[int], check_bounds: bool = True) -> torch.Tensor:
@@ -196,7 +214,7 @@ class Recording:
             st = C.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))
             _lib.check(_lib.lib().bde_voxelize_event_ranges(
                 C.c_void_p(self.xs.data_ptr()), C.c_void_p(self.ys.data_ptr()), C.c_void_p(self.ts.data_ptr()),
-                C.c_void_p(self.ps.data_ptr()), C.c_void_p(se[0].data_ptr()), C.c_void_p(se[1].data_ptr()), n,
+                C.c_void_p(self.ps.data_ptr()), self.ts.numel(), C.c_void_p(se[0].data_ptr()), C.c_void_p(se[1].data_ptr()), n,
                 self.num_bins, H, W, C.c_void_p(grids.data_ptr()), C.c_void_p(oob.data_ptr()), st))
         if check_bounds and int(oob.item()) != 0:
             raise IndexError(f'{int(oob.item())} events fall outside the {H}x{W} sensor '
@@ -204,7 +222,15 @@ class Recording:
         return grids
 
     def get_frame(self, index) -> np.ndarray:
-        return self.frames[index]
+        """Image `index` (uint8).  Files are read one image at a time, the way DynamicH5Dataset.get_frame does (:404-405);
+        the most recent ones are kept.  The arrays= path holds its frames already."""
+        if self.frames is not None:
+            return self.frames[index]
+        if index not in self._frame_cache:
+            if len(self._frame_cache) >= 64:
+                self._frame_cache.pop(next(iter(self._frame_cache)))
+            self._frame_cache[index] = np.asarray(self.h5_file['images/{}'.format(self._frame_names[index])][:])
+        return self._frame_cache[index]
 
     def item_times(self, index):
         """(ts_0, ts_k, dt) of item `index` as the reference computes them (:214-218,228-231)."""
@@ -217,7 +243,8 @@ class Recording:
         return ts_0, ts_k, ts_k - ts_0
 
     def __getitem__(self, index) -> Dict[str, torch.Tensor]:
-        assert 0 <= index < len(self), 'index {} out of bounds (0 <= x < {})'.format(index, len(self))
+        if not 0 <= index < len(self):
+            raise ItemIndexError(f'item {index} requested from a recording of {len(self)} items')
         voxel = self.voxels([index])[0]
         ts_0, ts_k, dt = self.item_times(index)
         if self.voxel_method['method'] == 'between_frames':

@@ -28,7 +28,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak (=
 SPLIT_BF16_PEAK_TFLOPS = 2500.0 / 6   # fp32-equivalent work on the bf16 matrix cores: dense bf16 peak / six MFMAs per fp32 block (csrc/conv_sb.h)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
 ATOMIC_PEAK_GBPS = 1300.0       # MI355X_MICROARCH.md, global float atomics: ~1.3 TB/s of added bytes chip-wide
-PMC_FILE = os.path.join(REPO, 'profiles', 'r2_pmc.json')
+PROFILE_TAG = 'r3'              # the committed rocprofv3 artefacts this line cites: profiles/<tag>_*
+PMC_FILE = os.path.join(REPO, 'profiles', PROFILE_TAG + '_pmc.json')
+if not os.path.exists(PMC_FILE):
+    PMC_FILE = os.path.join(REPO, 'profiles', 'r2_pmc.json')
 
 
 def log(msg):
@@ -362,14 +365,12 @@ def main():
     H, W, T, B = croper.height_crop_size, croper.width_crop_size, args.seq_len, args.batch
     # every rank reconstructs the same synthetic recording (its own replica, its own copy): the reference's frames
     # for it are committed, so every rank -- the broadcast receivers included -- can check what it computed
-    vox, n_events, vox_dt = workload.bench_voxels(T, (args.height, args.width), device, seed0=1000)
-    if B > 1:
-        vox = vox.repeat(1, B, 1, 1, 1)
+    fixture = workload.find_fixture(T, B, H, W, [args.height, args.width])
+    seed0 = fixture[1]['seed'] if fixture else workload.SEED0
+    vox, n_events, vox_dt = workload.bench_voxels(T, (args.height, args.width), device, seed0=seed0, batch=B)
     inputs = [{'events': vox[t]} for t in range(T)]
     log(f'voxel grids ready ({n_events} events in {vox_dt*1e3:.1f} ms)')
-    fmeta = workload.fixture_meta()
-    can_verify = bool(fmeta and (T, B, H, W) == (fmeta['T'], fmeta['B'], fmeta['H'], fmeta['W'])
-                      and [args.height, args.width] == fmeta['sensor'])
+    can_verify = fixture is not None
 
     L = _lib.lib()
     with torch.no_grad():
@@ -402,10 +403,24 @@ def main():
         # ---- the frames of the last timed step against the reference's ------------------------------
         verified, verr = None, None
         if can_verify:
-            ok, verr = workload.verify_against_fixture(torch.stack(last))
+            ok, verr = workload.verify_against_fixture(torch.stack(last), fixture[0])
             verified = bool(min_over_ranks(1.0 if ok else 0.0, device) > 0.5)
             verr = max_over_ranks(verr, device)
             log(f'last timed step vs reference frames: max abs err {verr:.2e} -> verified={verified}')
+        # ---- single stream: the same K steps with ONE sequence in flight (pipeline 1, graph replay): the latency-bound figure
+        model.set_tuning('pipeline', 1)
+        for _ in range(2):
+            model(inputs)
+        torch.cuda.synchronize(device)
+        single_graph = model.get_info('graphs_live') >= 1
+        barrier()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            model(inputs)
+        torch.cuda.synchronize(device)
+        barrier()
+        single_elapsed = time.perf_counter() - t1
         # ---- per-kernel spans: HIP events around every launch, on the launch stream.  Events recorded inside a
         # replayed hipGraph cannot be read back, so the spans come from a few extra EAGER, un-pipelined steps
         # run right after the timed region (same inputs, same kernels).
@@ -417,6 +432,7 @@ def main():
             model(inputs)
         torch.cuda.synchronize(device)
     elapsed = max_over_ranks(elapsed, device)
+    single_elapsed = max_over_ranks(single_elapsed, device)
     log(f'timed region done: {elapsed:.3f} s for {args.steps} steps')
 
     if rank == 0:
@@ -477,12 +493,19 @@ def main():
             'metric': 'reconstructed frames/sec at 5x240x180 voxels, seq_len=16',
             'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (bf16x3 split MFMA where conv_sb / winblock apply, f32 accumulate)', 'data': 'synthetic',
+            'single_stream': {'value': args.steps * T * B * world / single_elapsed, 'unit': 'frames/s',
+                              'ms_per_step': 1e3 * single_elapsed / args.steps, 'graph_replay': bool(single_graph),
+                              'what': f'the same {args.steps} steps with ONE sequence in flight per GPU (pipeline 1): per-sequence '
+                                      'latency; `value` overlaps `config.pipeline` independent sequences'},
+            'profile_set': f'profiles/{PROFILE_TAG}_* (rocprofv3 --kernel-trace --stats of this command and of --pipeline 1; PMC passes)',
             'verified': verified,
-            'verification': ({'against': 'tests/golden/e2e_bench_T16.npz (the reference\'s frames for these events)',
+            'verification': ({'against': f'{os.path.relpath(fixture[0], REPO)} (the reference\'s frames for these events)',
                               'what': 'frames of the last timed step (pipelined, graph replay), every rank', 'max_abs_err': verr,
                               'tolerance': workload.TOLERANCE} if can_verify else
-                             {'against': None, 'why': 'a reference fixture exists only for the default workload (16 x 5x180x240, B=1)'}),
+                             {'against': None, 'why': 'reference fixtures exist for BASELINE configs 2, 3 and 5 at full size only: '
+                                                      '16 x 5x180x240 B=1, 32 x 5x480x640 B=4, 64 x 5x720x1280 B=1'}),
             'config': {'workload': f'BDE2VID.forward config A (5 bins, 32 ch, depths [4,0,6], 16 heads, D=3), '
                                    f'{T} frames of 5x{args.height}x{args.width} (padded {H}x{W}), batch {B}, '
                                    f'random-init formula weights, one independent sequence per step per GPU',

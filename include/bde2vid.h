@@ -166,8 +166,10 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
                         int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream);
 
 /* The same for arbitrary, possibly overlapping windows [starts[w], ends[w]) (device int64 [nwin] each): the k_events and
- * t_seconds voxel methods with a sliding window (h5_dataset.py:277-302). */
-int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps,
+ * t_seconds voxel methods with a sliding window (h5_dataset.py:277-302).  n_events = length of the four columns: window
+ * bounds beyond it are clamped on the device (what an h5py slice does with a file whose attributes overstate its datasets),
+ * so no window can read past the columns. */
+int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, int64_t n_events,
                               const int64_t* starts, const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H,
                               int32_t W, float* grids, int32_t* oob_count, void* stream);
 /* Binning kernel behind all bde_voxelize* calls of the process: 0 (default) = a workgroup per (window, pixel tile)

@@ -145,6 +145,45 @@ def gen_bench_fixture():
                    sensor=[sh, sw], events_per_frame=sh * sw // 2)
 
 
+# BASELINE configs 3 and 5 at FULL size (workspaces pass 2^31 elements there): the same pipeline as gen_bench_fixture.
+# Batch element b of frame t is the grid of the events with seed seed0 + b*T + t (bde2vid_amd/workload.py::bench_voxels).
+# name: (sensor H, W, T, B, event seed of frame 0, stored stride)
+BENCH_FULLSIZE = {
+    'e2e_bench_480x640_T32_B4': (480, 640, 32, 4, 1000, 16),
+    'e2e_bench_720x1280_T64': (720, 1280, 64, 1, 1000, 16),
+}
+
+
+def gen_bench_fullsize(only=None):
+    from bde2vid_amd.synth import synthetic_events
+    import time
+    EU = ref_import.import_event_utils()
+    Croper = ref_import.import_croper()
+    cfg = canonical()
+    for name, (sh, sw, T, B, seed0, stride) in BENCH_FULLSIZE.items():
+        if only and name not in only:
+            continue
+        model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+        crop = Croper(cfg.num_encoders)
+        inputs = []
+        for t in range(T):
+            vs = []
+            for b in range(B):
+                xs, ys, ts, ps = synthetic_events(sh * sw // 2, sh, sw, seed0 + b * T + t)
+                vs.append(EU.events_to_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts),
+                                                   torch.from_numpy(ps), cfg.num_bins, sensor_size=(sh, sw)))
+            inputs.append({'events': crop.pad(torch.stack(vs))})
+        H, W = inputs[0]['events'].shape[-2:]
+        t0 = time.time()
+        print(name, 'running the reference ...', flush=True)
+        with torch.no_grad():
+            ys_ = model(inputs)
+        print(name, f'{time.time() - t0:.0f} s', flush=True)
+        _store_sampled(name, cfg, torch.stack(ys_).numpy(), stride, int(H), int(W), T, B, seed0,
+                       sensor=[sh, sw], events_per_frame=sh * sw // 2)
+        del ys_, inputs, model
+
+
 def gen_longT():
     for name, (kw, H, W, T, B, seed, ccl, stride) in LONGT_CASES.items():
         cfg = _cfg(kw)

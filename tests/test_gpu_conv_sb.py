@@ -175,3 +175,37 @@ def test_recurrent_step_on_split_bf16(model_a):
         m.set_tuning('lstm_sb', 0)
     for (h0, c0), (h1, c1) in zip(ref, got):
         assert maxabs(h1, h0) <= 2e-5 and maxabs(c1, c0) <= 2e-5
+
+
+def test_non_finite_activations_same_class_on_both_arithmetic_paths(model_a):
+    """A NaN activation must come out as NaN at exactly the output pixels its 3x3 footprint reaches, on the fp32 kernels
+    (conv_sb 0) and on the split-bf16 ones (conv_sb 1) alike, as torch's convolution gives them; an infinite activation
+    rides in the leading bf16 term alone (sb_split3), so it stays non-finite on the same footprint on both paths
+    (Inf * w_mid can turn an Inf into a NaN on the split path: INTEGRATION.md §3)."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    level, C, N, H, W = 2, cfg.enc_out(2), 16, 23, 30
+    x = torch.from_numpy(dense_like((2, N, C, H, W), 990))
+    x[0, 3, 17, 5, 7] = float('nan')
+    x[1, 9, 100, 20, 29] = float('inf')
+    x[1, 2, 5, 0, 0] = float('-inf')
+    ref = []
+    for d, name in enumerate(('forward_encoder', 'backward_encoder')):
+        w = sd[f'{O.P}{name}.{level}.recurrent_block.Gates.weight'][:, :C]
+        ref.append(F.conv2d(x[d], w, sd[f'{O.P}{name}.{level}.recurrent_block.Gates.bias'], padding=1))
+    ref = torch.stack(ref)
+    xd = x.cuda()
+    outs = {}
+    for sb in (0, 1):
+        m.set_tuning('conv_sb', sb)
+        outs[sb] = ops.gate_conv(m, level, xd).cpu()
+    m.set_tuning('conv_sb', 1)
+    assert m.get_info('sb_gx2') == 1
+    for sb, y in outs.items():
+        assert torch.equal(torch.isfinite(y), torch.isfinite(ref)), f'conv_sb={sb}: non-finite footprint differs from torch'
+        assert torch.isnan(y[0, 3, :, 4:7, 6:9]).all()                       # the NaN's 3x3 footprint, every output channel
+        fin = torch.isfinite(ref)
+        assert maxabs(y[fin], ref[fin]) <= 1e-4 * float(ref[fin].abs().max())
+    assert torch.equal(torch.isnan(outs[0][0]), torch.isnan(ref[0]))        # NaN in, NaN out: identical on the fp32 path
+    assert torch.equal(torch.isnan(outs[1][0]), torch.isnan(ref[0]))        # ... and on the split path

@@ -243,8 +243,10 @@ def test_bench_workload_matches_reference_in_serving_mode():
     from bde2vid_amd import canonical
     from bde2vid_amd.model import build_model
     from bde2vid_amd.weights import formula_state_dict
-    from bde2vid_amd.workload import bench_voxels, verify_against_fixture
+    from bde2vid_amd.workload import bench_voxels, verify_against_fixture, find_fixture
     z, meta = load_golden('e2e_bench_T16')
+    fixture_path, fmeta = find_fixture(meta['T'], meta['B'], meta['H'], meta['W'], meta['sensor'])
+    assert fmeta == meta
     cfg = canonical()
     m = build_model(cfg, formula_state_dict(cfg, meta['weight_seed']), 'cuda:0')
     vox, n_events, _ = bench_voxels(meta['T'], tuple(meta['sensor']), 'cuda:0', seed0=meta['seed'])
@@ -258,9 +260,42 @@ def test_bench_workload_matches_reference_in_serving_mode():
     for o in outs:
         y = torch.stack(o)
         assert_sampled(y, z, meta, TOL, 1e-5)
-        ok, err = verify_against_fixture(y)
+        ok, err = verify_against_fixture(y, fixture_path)
         assert ok and err <= TOL
     m.set_tuning('pipeline', 1)
+
+
+@pytest.mark.parametrize('name', ['e2e_bench_480x640_T32_B4', 'e2e_bench_720x1280_T64'])
+def test_baseline_configs_3_and_5_at_full_size(name):
+    """BASELINE.json configs 3 and 5 at their FULL sizes (VGA T=32 B=4 with four different streams in the batch; HD T=64):
+    the gate x-part workspace alone is 5.0e9 / 7.5e9 floats there, past 2^31 elements, so every index product of the path
+    is exercised where an `int` would wrap.  Inputs = bench.py's workload (HIP binning of the synthetic events); expected =
+    what the REFERENCE computed for the same events in the build container (oracle/gen_golden.py::gen_bench_fullsize):
+    pixels at stride 16 plus per-frame mean / std.  Eager call, then the graph replay of the same shape."""
+    from bde2vid_amd import canonical
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.weights import formula_state_dict
+    from bde2vid_amd.workload import bench_voxels, verify_against_fixture, find_fixture
+    z, meta = load_golden(name)
+    cfg = canonical()
+    m = build_model(cfg, formula_state_dict(cfg, meta['weight_seed']), 'cuda:0')
+    T, B = meta['T'], meta['B']
+    vox, n_events, _ = bench_voxels(T, tuple(meta['sensor']), 'cuda:0', seed0=meta['seed'], batch=B)
+    assert n_events == T * B * meta['events_per_frame'] and tuple(vox.shape) == (T, B, 5, meta['H'], meta['W'])
+    inputs = [{'events': vox[t]} for t in range(T)]
+    path, fmeta = find_fixture(T, B, meta['H'], meta['W'], meta['sensor'])
+    assert fmeta == meta
+    with torch.no_grad():
+        for rep in range(3):                              # eager, capture, replay
+            y = torch.stack(m(inputs))
+            torch.cuda.synchronize()
+            assert_sampled(y, z, meta, TOL, 1e-5)
+            ok, err = verify_against_fixture(y, path)
+            assert ok and err <= TOL, (rep, err)
+            del y
+    assert m.get_info('graphs_live') == 1
+    del m
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('name', sorted(LONGT_CASES))
@@ -371,3 +406,27 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['verified'] is True and d['verification']['max_abs_err'] <= 2e-4
+
+
+def test_nan_voxel_grid_gives_the_reference_nan_frames():
+    """A zero-duration event window makes the reference's voxel grid NaN (event_utils.py:489-495), and -- torch's ReLU /
+    ReLU6 hand a NaN on, the recurrence and the window attention spread it -- every frame of the sequence NaN (checked on
+    the oracle in the build container: 100 % of the pixels of all five frames).  The same must happen here: a max()-based
+    activation would silently turn the NaN into a zero and return plausible-looking frames."""
+    from oracle import bde2vid_oracle as O
+    from bde2vid_amd.model import build_model
+    z, meta = load_golden('e2e_tiny')
+    cfg, sd, xs = case_from_meta(meta)
+    xs = [x.copy() for x in xs]
+    xs[2][0, :, 20:23, 30:34] = np.nan                                      # a patch of frame 2
+    m = build_model(cfg, sd, 'cuda:0')
+    with torch.no_grad():
+        y = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in xs])).cpu()
+        ref = torch.stack(O.forward(sd, cfg, [{'events': torch.from_numpy(x)} for x in xs]))
+    assert torch.isnan(ref).all()
+    assert torch.equal(torch.isnan(y), torch.isnan(ref))
+    # and the model object is not poisoned: the next call on clean inputs reproduces the golden frames
+    with torch.no_grad():
+        xs2 = case_from_meta(meta)[2]
+        y2 = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in xs2]))
+    assert maxabs(y2, z['out']) <= TOL

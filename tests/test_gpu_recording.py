@@ -64,6 +64,45 @@ def test_out_of_range_item_raises_like_the_reference(golden):
         ds[last]
     with pytest.raises(Exception, match='length of zero'):
         Recording(arrays=rec, voxel_method={'method': 'k_events', 'k': 10 ** 7, 'sliding_window_w': 0})
+    with pytest.raises(AssertionError):                      # the reference asserts (h5_dataset.py:210) ...
+        ds[len(ds)]
+    with pytest.raises(IndexError):                          # ... and Python's iteration protocol wants an IndexError
+        ds[-1]
+    with pytest.raises(ValueError, match='unknown voxel method'):
+        Recording(arrays=rec, voxel_method={'method': 'every_other_tuesday'})
+
+
+def test_attributes_that_overstate_the_columns_cannot_reach_past_them(golden):
+    """A truncated / inconsistent file: `num_events` and the images' `event_idx` claim more events than the datasets hold
+    (ADVICE r2).  num_events is clamped to the columns, the host check rejects windows past them, and a window handed to the
+    binning entry point directly is clamped on the device instead of read out of bounds."""
+    import ctypes as C
+    from bde2vid_amd import _lib
+    from bde2vid_amd.recording import Recording
+    z, meta, rec = golden
+    lying = dict(rec)
+    lying['num_events'] = int(rec['num_events']) + 5000
+    lying['event_idx'] = [int(v) for v in rec['event_idx'][:-1]] + [int(rec['num_events']) + 4000]
+    ds = Recording(arrays=lying)
+    assert ds.num_events == len(rec['ts'])
+    with pytest.raises(IndexError, match='out of bounds'):
+        ds.voxels([len(ds) - 1])
+    ok = ds.voxels(range(len(ds) - 1))
+    ref = Recording(arrays=rec).voxels(range(len(ds) - 1))
+    assert torch.equal(ok, ref)
+    # straight through the C ABI: [n - 100, n + 10^6) must behave as [n - 100, n)
+    n = ds.ts.numel()
+    H, W = ds.sensor_resolution
+
+    def run(end):
+        se = torch.tensor([[n - 100], [end]], dtype=torch.int64, device='cuda')
+        g = torch.empty((1, 5, H, W), dtype=torch.float32, device='cuda')
+        _lib.check(_lib.lib().bde_voxelize_event_ranges(
+            C.c_void_p(ds.xs.data_ptr()), C.c_void_p(ds.ys.data_ptr()), C.c_void_p(ds.ts.data_ptr()), C.c_void_p(ds.ps.data_ptr()),
+            n, C.c_void_p(se[0].data_ptr()), C.c_void_p(se[1].data_ptr()), 1, 5, H, W, C.c_void_p(g.data_ptr()), None, None))
+        torch.cuda.synchronize()
+        return g
+    assert torch.equal(run(n + 10 ** 6), run(n))
 
 
 def test_tile_binning_equals_atomic_scatter():
