@@ -23,6 +23,7 @@
 #include "token_fused.h"
 #include "lstm16.h"
 #include "winblock.h"
+#include "winblock_sb.h"
 #include "wideblock.h"
 #include "attn_mfma.h"
 #include "conv_vec.h"
@@ -337,6 +338,25 @@ static long pack16x4(Arena& ar, const float* w, int rows, int K) {
     return off;
 }
 
+// winblock_sb.h: rows x K as three bf16 terms in A-fragment order of v_mfma_f32_16x16x32_bf16:
+// [row tile 16][k-step 32][term][64 lanes][8]: lane l = W[16 tile + (l & 15)][32 kstep + 8 (l >> 4) + j]; K % 32 == 0.
+static long pack16_split(Arena& ar, const float* w, int rows, int K) {
+    const int nrt = cdiv(rows, 16), nks = K / 32;
+    const long n_u16 = (long)nrt * nks * 3 * 64 * 8;
+    const long off = ar.alloc(n_u16 / 2);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + off);
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = rt * 16 + (l & 15), k = ks * 32 + 8 * (l >> 4) + j;
+                    unsigned short t3[3];
+                    sb_split3(r < rows ? w[(long)r * K + k] : 0.f, t3[0], t3[1], t3[2]);
+                    for (int t = 0; t < 3; ++t) dst[((((long)rt * nks + ks) * 3 + t) * 64 + l) * 8 + j] = t3[t];
+                }
+    return off;
+}
+
 // Weight fragments of the recurrent step kernel (lstm16.h):
 // [hidden16 block][chunk of 8 channels][tap][k4][64 lanes][gate], lane l = W[gate*Ch + hb*16 + (l&15)][chunk*8 + k4*4 + (l>>4)][tap]
 // (the four gate fragments of a lane are adjacent: one 16-byte LDS read fetches them).
@@ -482,6 +502,7 @@ struct AttnBlock {
     PackedLayer qkv, proj, fc1, fc2;
     long proj16 = -1, fc1_16 = -1, fc2_16 = -1, qkv16 = -1;   // 16x16x4 packings for token_fused.h
     long projW = -1, fc1W = -1, fc2W = -1, qkvW = -1;         // four-k-steps-per-load packings for wideblock.h
+    long projS = -1, fc1S = -1, fc2S = -1, qkvS = -1;         // split-bf16 packings for winblock_sb.h
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -566,6 +587,7 @@ struct bde_model {
     Tuning tune;                  // launch-shape overrides (common.h), per model
     int lstm_hc8 = -1;            // recurrent step with 8-channel workgroups: -1 auto (lstm16_wants_hc8), 0 never, 1 always
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
+    int winblock_sb = 1;          // ... with its GEMM phases on the bf16 matrix cores, three-term split operands (winblock_sb.h)
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
     int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
@@ -828,6 +850,12 @@ static int build_packed(bde_model* m) {
                 ab.fc1W = pack16x4(ar, fc1.w.data(), hid, C);
                 ab.fc2W = pack16x4(ar, fc2.w.data(), C, hid);
                 ab.qkvW = pack16x4(ar, qkv.w.data(), 3 * C, C);
+            }
+            if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
+                ab.projS = pack16_split(ar, proj.w.data(), C, C);
+                ab.fc1S = pack16_split(ar, fc1.w.data(), hid, C);
+                ab.fc2S = pack16_split(ar, fc2.w.data(), C, hid);
+                ab.qkvS = pack16_split(ar, qkv.w.data(), 3 * C, C);
             }
             if (C % 16 == 0 && token_lds_bytes(C) <= 150 * 1024) {
                 ab.proj16 = pack16(ar, proj.w.data(), C, C);
@@ -1409,10 +1437,17 @@ static int run_attention_frame_win(bde_model* m, int l, const float* const* fram
         a.wfc1 = m->P(ab.fc1_16);  a.bfc1 = m->P(ab.fc1.b_off);  a.sfc1 = m->P(ab.fc1.s_off);
         a.wfc2 = m->P(ab.fc2_16);  a.bfc2 = m->P(ab.fc2.b_off);
         a.biasF = m->P(ab.biasF_off);
+        const bool sbk = m->winblock_sb && ab.qkvS >= 0;
+        if (sbk) {
+            a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(ab.qkvS));
+            a.wprojS = reinterpret_cast<const unsigned short*>(m->P(ab.projS));
+            a.wfc1S = reinterpret_cast<const unsigned short*>(m->P(ab.fc1S));
+            a.wfc2S = reinterpret_cast<const unsigned short*>(m->P(ab.fc2S));
+        }
         a.stamps = m->tok_stamps;
         a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw; a.pt = ph / 2; a.pl = pw / 2;
         a.dilated = (i % 2) == 1 ? 1 : 0;                    // DTransformer.py:362
-        { ProfScope ps(m, pname("winblock", l), s); BDE_TRY(winblock_launch(a, B, s)); }
+        { ProfScope ps(m, pname("winblock", l), s); BDE_TRY(sbk ? winblock_sb_launch(a, B, s) : winblock_launch(a, B, s)); }
         x = dst;
     }
     return BDE_OK;
@@ -1995,6 +2030,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         m->winblock = (int)value;
         return BDE_OK;
     }
+    if (std::string(key) == "winblock_sb") { m->winblock_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "wide") {
         if (m->wide != (int)value)
             for (auto& w : m->wslots) w.release();
@@ -2038,6 +2074,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "last_stream") *value = (int64_t)(uintptr_t)m->last_stream;   // internal stream of the latest pipelined call
     else if (k == "device") *value = m->device;
     else if (k == "winblock") *value = m->winblock;
+    else if (k == "winblock_sb") *value = m->winblock_sb;
     else if (k == "wide") *value = m->wide;
     else if (k == "conv_sb") *value = m->conv_sb;
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;

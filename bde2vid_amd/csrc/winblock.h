@@ -58,6 +58,9 @@ struct WinArgs {
     const float *wproj, *bproj;                 // packed16 [4][16][64], [64]
     const float *wfc1, *bfc1, *sfc1;            // packed16 [16][16][64], [256], [256]
     const float *wfc2, *bfc2;                   // packed16 [4][64][64], [64]
+    // winblock_sb.h: the same four weight matrices as three bf16 terms in A-fragment order of the 16x16x32 MFMA,
+    // [row tile 16][k-step 32][term][64 lanes][8]
+    const unsigned short *wqkvS, *wprojS, *wfc1S, *wfc2S;
     const float* biasF;             // [16 heads][4 query tiles][10 key tiles][64 lanes][4]: a lane's four C-operand values of a score tile as one 16-byte load, log2(e) folded,
                                     // keys beyond D*49 = -1e30
     int nslots;                     // D
@@ -585,9 +588,8 @@ constexpr size_t winblock_lds_bytes() {
     return (size_t)(2 * WB_NT * WB_C * 16 + 160 * WB_VP + 4 * WB_C * 16 + 320 + 1024 + 64 + WB_C * 16 + 512) * sizeof(float);
 }
 
-static int winblock_launch(WinArgs a, int B, hipStream_t stream) {
-    static unsigned char raised[BDE_MAX_DEVICES];
-    BDE_HIP(raise_dynamic_lds(raised, (const void*)winblock_kernel));
+// window grid and the pixels a dilated block's fold never writes (host side of WinArgs)
+static void winblock_geometry(WinArgs& a) {
     a.nWw = a.Wp / 7;
     a.nWin = (a.Hp / 7) * a.nWw;
     a.nA = a.nB = a.nrowsA = a.ncolsB = 0;
@@ -602,6 +604,12 @@ static int winblock_launch(WinArgs a, int B, hipStream_t stream) {
         a.nB = (a.H - a.nrowsA) * a.ncolsB;
     }
     a.ke = cdiv(a.nA + a.nB, a.nWin);
+}
+
+static int winblock_launch(WinArgs a, int B, hipStream_t stream) {
+    static unsigned char raised[BDE_MAX_DEVICES];
+    BDE_HIP(raise_dynamic_lds(raised, (const void*)winblock_kernel));
+    winblock_geometry(a);
     int extra = 0;
     if (a.ke > 15) { a.ke = 0; extra = cdiv(a.nA + a.nB, 64); }
     hipLaunchKernelGGL(winblock_kernel, dim3(a.nWin + extra, 1, B), dim3(1024), winblock_lds_bytes(), stream, a);

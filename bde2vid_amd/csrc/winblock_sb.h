@@ -1,0 +1,641 @@
+// winblock_kernel (winblock.h) with its four GEMM phases -- q|k|v, proj, fc1, fc2: 1.53 of the block's 2.0 GFLOP and half of
+// its cycles on v_mfma_f32_16x16x4_f32 -- moved to the bf16 matrix cores with three-term split operands (conv_sb.h's
+// arithmetic: a b ~= a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1, fp32 accumulate, fp32-equivalent accuracy):
+// per 16 x 16 output tile and K = 64, 12 v_mfma_f32_16x16x32_bf16 (16 cycles each) instead of 16 fp32 MFMAs (32 cycles each).
+// Scores, softmax and p*v are winblock.h's, unchanged (K = head_dim = 4 is the fp32 16x16x4 MFMA's own shape).
+//
+// What changes around the GEMMs:
+//   * weights: split at pack time into A-fragment order of the 16x16x32 MFMA, [row tile 16][k-step 32][term 3][64 lanes][8]
+//     (lane l = W[16 tile + (l & 15)][32 kstep + 8 (l >> 4) + j]), 16-byte loads L2 -> registers, a phase ahead;
+//   * activations: every GEMM's token operand lives in LDS as three bf16 images in B-fragment order
+//     [term][token tile 16][chunk of 8 channels][16 tokens][8 channels]: a lane's fragment is one ds_read_b128, the 16
+//     lanes of a read group hit 16 different bank groups.  The gather splits the window's tokens once as they arrive
+//     (v_cvt_pk_bf16_f32: 5.5 vector instructions per element), the attention phase writes its output already split,
+//     the proj / fc1 epilogues split x1 / the hidden activations for the GEMM that follows;
+//   * LDS: the split tokens (60 KB for 10 token tiles) do not fit beside K, V and Q (100 KB): the q|k|v GEMM runs in two
+//     passes over a 36 KB operand buffer -- token tiles 0..5 with the query projection, then tiles 6..9, whose tokens wait
+//     in registers meanwhile; both passes give every wave the same number of tiles (4 + 2).
+//   * the query frame is kept in fp32 as well ([4][64][16], the residual x + proj(.)); pixels outside every dilated
+//     window ride in token columns 49..63 as in winblock.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "winblock.h"
+#include "conv_sb.h"
+
+namespace bde {
+
+constexpr int WS_XT = 0;                                   // f32 [4][64][16]: x of the query tokens (+ carried pixels), then x1
+constexpr int WS_XS = WS_XT + 4 * WB_C * 16 * 4;           // bf16 x 3 operand tiles [term][6 tiles][8 chunks][16 tokens][8 ch]
+constexpr int WS_XS_TILE = 2048;
+constexpr int WS_XS_TERM = 6 * WS_XS_TILE;
+constexpr int WS_KL = WS_XS + 3 * WS_XS_TERM;              // f32 [10][64][16]
+constexpr int WS_VL = WS_KL + WB_NT * WB_C * 16 * 4;       // f32 [160][68]
+constexpr int WS_QL = WS_VL + 160 * WB_VP * 4;             // f32 [4][64][16]
+constexpr int WS_ST = WS_QL + 4 * WB_C * 16 * 4;           // mu[160] | rstd[160]
+constexpr int WS_PR = WS_ST + 320 * 4;                     // biases and LayerNorm row sums, as in winblock.h
+constexpr int WS_PIX = WS_PR + 1024 * 4;
+constexpr int WS_S2 = WS_PIX + 64 * 4;
+constexpr int WS_END = WS_S2 + 512 * 4;
+constexpr int WS_HID = WS_KL;                              // bf16 x 3 hidden activations [term][4 tiles][32 chunks][16][8] over K | V | Q
+constexpr int WS_HID_TILE = 32 * 256;
+constexpr int WS_HID_TERM = 4 * WS_HID_TILE;
+static_assert(WS_HID + 3 * WS_HID_TERM <= WS_ST, "hidden activations overlay K | V | Q only");
+static_assert(WS_END <= 160 * 1024, "LDS budget of one workgroup per CU");
+
+typedef float wsf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wsb2 __attribute__((ext_vector_type(2)));
+// two fp32 values -> their bf16 roundings in one dword (v_cvt_pk_bf16_f32, round to nearest even).  Inline asm on purpose: as a
+// vector conversion it seeds the SLP vectorizer, which then turns the softmax / p*v accumulators feeding it into v_pk_*_f32
+// pairs -- 120 spilled registers in a phase that sits at the 128-register cap.
+__device__ __forceinline__ unsigned ws_pk(float a, float b) {
+    unsigned d;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// (x0, x1) = hi + mid + lo, each term a packed bf16 pair; the remainders are exact in fp32
+__device__ __forceinline__ void ws_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = ws_pk(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = ws_pk(r0, r1);
+    const float q0 = r0 - __builtin_bit_cast(float, mid << 16), q1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = ws_pk(q0, q1);
+}
+// one 16 x 16 x 32 k-step of an fp32-equivalent product: small terms first, the leading product last
+__device__ __forceinline__ f32x4 ws_mma6(const sb8 (&af)[3], const sb8 (&bf)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* XT = reinterpret_cast<float*>(smem + WS_XT);
+    unsigned char* XS = smem + WS_XS;
+    float* KL = reinterpret_cast<float*>(smem + WS_KL);
+    float* VL = reinterpret_cast<float*>(smem + WS_VL);
+    float* QL = reinterpret_cast<float*>(smem + WS_QL);
+    float* ST = reinterpret_cast<float*>(smem + WS_ST);
+    float* PR = reinterpret_cast<float*>(smem + WS_PR);
+    int* PIX = reinterpret_cast<int*>(smem + WS_PIX);
+    float* S2 = reinterpret_cast<float*>(smem + WS_S2);
+    unsigned char* HS = smem + WS_HID;
+    float* pbqkv = PR, *psqkv = PR + 192, *pbproj = PR + 384, *pbfc1 = PR + 448, *psfc1 = PR + 704, *pbfc2 = PR + 960;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: lives in a scalar register
+    const int g4 = lane >> 4, col = lane & 15;
+    const int b = blockIdx.z;
+    const int HW = a.H * a.W;
+    const bool mlp_only = (int)blockIdx.x >= a.nWin;
+    const int ntok = mlp_only ? 64 : WB_TOK * a.nslots;
+
+    WB_STAMP(0);
+    // ---- weight fragments of the first contraction, in flight while the tokens are gathered ---------
+    const int rtkv = 4 + (wave & 7), rtq = wave & 3;
+    sb8 akv[2][3], aqw[2][3];
+    if (!mlp_only) {
+        const sb8* wq = reinterpret_cast<const sb8*>(a.wqkvS) + lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                akv[ks][k] = wq[((rtkv * 2 + ks) * 3 + k) * 64];
+                aqw[ks][k] = wq[((rtq * 2 + ks) * 3 + k) * 64];
+            }
+    }
+    for (int i = tid; i < 1024; i += 1024) {
+        float v;
+        if (i < 192) v = a.bqkv[i];
+        else if (i < 384) v = a.sqkv[i - 192];
+        else if (i < 448) v = a.bproj[i - 384];
+        else if (i < 704) v = a.bfc1[i - 448];
+        else if (i < 960) v = a.sfc1[i - 704];
+        else v = a.bfc2[i - 960];
+        PR[i] = v;
+    }
+
+    // ---- gather: wave = token tile, lane = (token col, quarter g4): channels 8 g4 .. + 7 and 32 + 8 g4 .. + 7 (chunks g4, 4 + g4) ----
+    // waves 0..9: the window's tokens of all frames (query frame first); wave 10: pixels outside every dilated window
+    // carried in token columns 49..63; mlp-only workgroups: waves 0..3 = 64 such pixels.
+    float xv[16];                                   // this thread's 16 channels of its token
+    bool have_tok = false;                          // the thread holds a token of tiles 0..9 (or an mlp-only pixel)
+    {
+        const int nextra = a.nA + a.nB;
+        auto uncovered_pixel = [&](int e) {         // e-th pixel outside every dilated window
+            int y, x;
+            if (e < a.nA) {
+                const int ri = e / a.W;
+                y = a.rowsA[ri];
+                x = e - ri * a.W;
+            } else {
+                const int e2 = e - a.nA;
+                const int yi = e2 / a.ncolsB;
+                x = a.colsB[e2 - yi * a.ncolsB];
+                y = yi;
+                for (int k = 0; k < a.nrowsA; ++k)
+                    if (y >= a.rowsA[k]) ++y;
+            }
+            return y * a.W + x;
+        };
+        const int u = wave * 16 + col;
+        const bool carried = !mlp_only && wave == 10;
+        int sl = 0, pix = -1;
+        bool active = false;
+        if (carried) {
+            const int e = (int)blockIdx.x * a.ke + col;
+            active = col < 15;
+            if (col < a.ke && e < nextra) pix = uncovered_pixel(e);
+        } else if (mlp_only) {
+            const int e = ((int)blockIdx.x - a.nWin) * 64 + u;
+            active = wave < 4;
+            if (active && e < nextra) pix = uncovered_pixel(e);
+        } else if (wave < 10) {
+            active = true;
+            if (u < ntok) {
+                int tok = u;
+                if (u >= WB_TOK) {
+                    const int v = u - WB_TOK;
+                    sl = 1 + v / WB_TOK;
+                    tok = v - (sl - 1) * WB_TOK;
+                }
+                const int win = blockIdx.x;
+                const int wi = win / a.nWw, wj = win - wi * a.nWw;
+                const int ta = tok / 7, tb = tok - ta * 7;
+                const int step = a.dilated ? 2 : 1;
+                const int rp = wi * 7 + ta * step, cp = wj * 7 + tb * step;
+                const int ry = rp - a.pt, rx = cp - a.pl;
+                if (rp < a.Hp && cp < a.Wp && ry >= 0 && ry < a.H && rx >= 0 && rx < a.W) pix = ry * a.W + rx;
+            }
+        }
+        if (g4 == 0 && active) {
+            if (carried) PIX[WB_TOK + col] = pix;
+            else if (u < 64 && (mlp_only || u < WB_TOK)) PIX[u] = pix;
+        }
+        const float* sp = a.slot[sl];
+        const bool live = active && pix >= 0 && sp != nullptr;
+        // pointer select + unconditional loads (a load under a per-lane branch costs a vmcnt(0) join)
+        const float4* src = reinterpret_cast<const float4*>(live ? sp + b * a.slot_bs[sl] + (long)pix * WB_C : a.slot[0]);
+        float4 v[4];
+        v[0] = src[live ? 2 * g4 : 0];
+        v[1] = src[live ? 2 * g4 + 1 : 0];
+        v[2] = src[live ? 8 + 2 * g4 : 0];
+        v[3] = src[live ? 9 + 2 * g4 : 0];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float w[4] = {live ? v[f].x : 0.f, live ? v[f].y : 0.f, live ? v[f].z : 0.f, live ? v[f].w : 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[4 * f + e] = w[e];
+                s1 += w[e];
+                s2 += w[e] * w[e];
+            }
+        }
+        s1 += wb_shfl_xor(s1, 16);
+        s2 += wb_shfl_xor(s2, 16);
+        s1 += wb_shfl_xor(s1, 32);
+        s2 += wb_shfl_xor(s2, 32);
+        have_tok = active && !carried;
+        // fp32 copy for the residual: the query frame's tokens (tiles 0..2 and token 48), the carried pixels (tile 3,
+        // columns 1..15), all four tiles of an mlp-only workgroup
+        int xt_col = -1;
+        if (carried) xt_col = 48 + 1 + col;
+        else if (mlp_only) { if (active) xt_col = u; }
+        else if (u < WB_TOK) xt_col = u;
+        if (xt_col >= 0 && active) {
+            float* dst = XT + (xt_col >> 4) * WB_C * 16 + (xt_col & 15);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dst[((k < 8 ? 8 * g4 : 24 + 8 * g4) + k) * 16] = xv[k];
+        }
+        if (mlp_only && active) {                  // x1 = x: LayerNorm2 sums in the layout the proj epilogue leaves
+            S2[(g4 * 64 + u) * 2] = g4 == 0 ? s1 : 0.f;
+            S2[(g4 * 64 + u) * 2 + 1] = g4 == 0 ? s2 : 0.f;
+        }
+        if (g4 == 0 && have_tok && !mlp_only) {
+            const float mean = s1 * (1.f / WB_C);
+            const float var = fmaxf(s2 * (1.f / WB_C) - mean * mean, 0.f);
+            ST[u] = mean;
+            ST[160 + u] = __builtin_amdgcn_rsqf(var + 1e-5f);
+        }
+    }
+    // this thread's token as three bf16 terms into operand tile `jl` of XS (chunks g4 and 4 + g4)
+    auto write_split = [&](int jl) {
+        unsigned t[3][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ws_split2(xv[8 * h + 2 * p], xv[8 * h + 2 * p + 1], t[0][h][p], t[1][h][p], t[2][h][p]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *reinterpret_cast<uint4*>(XS + k * WS_XS_TERM + jl * WS_XS_TILE + (4 * h + g4) * 256 + col * 16) =
+                    uint4{t[k][h][0], t[k][h][1], t[k][h][2], t[k][h][3]};
+    };
+    if (have_tok && (mlp_only || wave < 6)) write_split(wave);
+    wb_sync();
+    WB_STAMP(1);
+
+    // B-operand fragments of token tile `jl` of an operand region (chunk stride 256 B, tile stride `tile_b`, term stride `term_b`)
+    auto load_b = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g4) * 256 + col * 16);
+    };
+
+    sb8 a1[2][3];                                  // fc1 fragments of this wave's row tile, fetched a phase early
+    if (mlp_only) {
+        const sb8* w1 = reinterpret_cast<const sb8*>(a.wfc1S) + lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a1[ks][k] = w1[((wave * 2 + ks) * 3 + k) * 64];
+    } else {                                       // (else, not a second if: a1 must not be live across the attention phase)
+        // ---- k|v of all frames (8 row tiles x 10 token tiles) and q of the query frame (4 x 4), two passes ------------
+        const int gp = wave >> 3;
+        auto kv_tile = [&](int j, int jl) {
+            sb8 b0[3], b1[3];
+            load_b(XS, WS_XS_TERM, WS_XS_TILE, jl, 0, b0);
+            load_b(XS, WS_XS_TERM, WS_XS_TILE, jl, 1, b1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ws_mma6(akv[0], b0, acc);
+            acc = ws_mma6(akv[1], b1, acc);
+            const int u = j * 16 + col;
+            const float mu = ST[u], rs = ST[160 + u];
+            const int row0 = rtkv * 16 + g4 * 4;           // row in q|k|v
+            float val[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[r] = rs * (acc[r] - mu * psqkv[row0 + r]) + pbqkv[row0 + r];
+            if (rtkv < 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) KL[(j * WB_C + (row0 - 64) + r) * 16 + col] = val[r];
+            } else {
+                *reinterpret_cast<float4*>(VL + u * WB_VP + (row0 - 128)) = float4{val[0], val[1], val[2], val[3]};
+            }
+        };
+#pragma unroll 1
+        for (int jj = 0; jj < 3; ++jj) kv_tile(gp * 3 + jj, gp * 3 + jj);
+        {
+            const int j = wave >> 2;
+            sb8 b0[3], b1[3];
+            load_b(XS, WS_XS_TERM, WS_XS_TILE, j, 0, b0);
+            load_b(XS, WS_XS_TERM, WS_XS_TILE, j, 1, b1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ws_mma6(aqw[0], b0, acc);
+            acc = ws_mma6(aqw[1], b1, acc);
+            const int u = j * 16 + col;
+            const float mu = ST[u], rs = ST[160 + u];
+            const int row0 = rtq * 16 + g4 * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                QL[(j * WB_C + row0 + r) * 16 + col] = rs * (acc[r] - mu * psqkv[row0 + r]) + pbqkv[row0 + r];
+        }
+        wb_sync();                                  // every wave is done with operand tiles 0..5
+        if (wave >= 6 && wave < 10) write_split(wave - 6);
+        wb_sync();
+#pragma unroll 1
+        for (int jj = 0; jj < 2; ++jj) kv_tile(6 + gp * 2 + jj, gp * 2 + jj);
+        wb_sync();
+        WB_STAMP(2);
+
+        // ---- attention: wave = head (winblock.h, unchanged but for the store of its output) ----------------------------
+        sb8 ap[2][3];                              // proj fragments (4 row tiles x 4 token tiles, one per wave)
+        {
+            const int h = wave;
+            constexpr int NQT = 3;                 // query tiles on the MFMA path: queries 0..47; query 48 below
+            float kf[WB_NT], qf[NQT];
+#pragma unroll
+            for (int j = 0; j < WB_NT; ++j) kf[j] = KL[(j * WB_C + h * WB_HD + g4) * 16 + col];
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) qf[i] = QL[(i * WB_C + h * WB_HD + g4) * 16 + col];
+            const f32x4* bf = reinterpret_cast<const f32x4*>(a.biasF + (long)h * 4 * WB_NT * 256) + lane;
+            constexpr int HT = WB_NT / 2;
+            f32x4 sc[2][HT];
+#pragma unroll
+            for (int j = 0; j < HT; ++j) sc[0][j] = bf[j * 64];
+            float s48[4];
+            {
+                const int jt = min(col, WB_NT - 1);
+                const f32x4 b48 = *(reinterpret_cast<const f32x4*>(a.biasF + ((long)(h * 4 + 3) * WB_NT + jt) * 256) + g4 * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s48[r] = col < WB_NT ? b48[r] : -1e30f;
+            }
+            const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
+            float pm[NQT], pl[NQT], po[NQT][4];                        // per query tile: max, sum, p*v of this lane's keys
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) {
+                float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int cb = hf, nx = hf ^ 1;
+                    const int nt = (i * 2 + hf + 1);                     // next half-tile overall
+                    if (nt < 2 * NQT) {
+#pragma unroll
+                        for (int j = 0; j < HT; ++j) sc[nx][j] = bf[(nt * HT + j) * 64];
+                    }
+                    f32x4 vb[2][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vb[0][r] = *reinterpret_cast<const f32x4*>(vbase + ((hf * HT) * 16 + r) * WB_VP);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < HT; ++j)
+                        sc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[hf * HT + j], qf[i], sc[cb][j], 0, 0, 0);
+                    float m2 = mx;
+#pragma unroll
+                    for (int j = 0; j < HT; ++j) {
+                        m2 = wb_max3(m2, sc[cb][j][0], sc[cb][j][1]);
+                        m2 = wb_max3(m2, sc[cb][j][2], sc[cb][j][3]);
+                    }
+                    if (hf == 1) {
+                        const float corr = __builtin_amdgcn_exp2f(mx - m2);
+                        l *= corr; o0 *= corr; o1 *= corr; o2 *= corr; o3 *= corr;
+                    }
+                    mx = m2;
+#pragma unroll
+                    for (int j = 0; j < HT; ++j) {
+                        if (j + 1 < HT) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                vb[(j + 1) & 1][r] = *reinterpret_cast<const f32x4*>(vbase + ((hf * HT + j + 1) * 16 + r) * WB_VP);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float pr[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(sc[cb][j][r] - mx);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 v = vb[j & 1][r];
+                            l += pr[r];
+                            o0 += pr[r] * v[0];
+                            o1 += pr[r] * v[1];
+                            o2 += pr[r] * v[2];
+                            o3 += pr[r] * v[3];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                pm[i] = mx; pl[i] = l; po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
+            }
+            // ---- query 48: keys on the lanes ----------------------------------------------------------
+            float l48, o48[4];
+            {
+                const int jt = min(col, WB_NT - 1);
+                float q48[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) q48[c] = QL[(3 * WB_C + h * WB_HD + c) * 16];     // token 48 = tile 3, column 0
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s48[r] += q48[c] * KL[(jt * WB_C + h * WB_HD + c) * 16 + g4 * 4 + r];
+                float m48 = wb_max3(s48[0], s48[1], fmaxf(s48[2], s48[3]));
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) m48 = fmaxf(m48, wb_shfl_xor(m48, sh));
+                l48 = 0.f;
+                o48[0] = o48[1] = o48[2] = o48[3] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(s48[r] - m48);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(VL + (jt * 16 + g4 * 4 + r) * WB_VP + h * WB_HD);
+                    l48 += pr;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o48[c] += pr * v[c];
+                }
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {
+                    l48 += wb_shfl_xor(l48, sh);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o48[c] += wb_shfl_xor(o48[c], sh);
+                }
+            }
+            // merge the four key quarters of each query (lanes col, col+16, col+32, col+48)
+            float M[NQT], f[NQT];
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) M[i] = fmaxf(pm[i], wb_shfl_xor(pm[i], 16));
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) M[i] = fmaxf(M[i], wb_shfl_xor(M[i], 32));
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) {
+                f[i] = __builtin_amdgcn_exp2f(pm[i] - M[i]);
+                pl[i] *= f[i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) po[i][c] *= f[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) {
+                pl[i] += wb_shfl_xor(pl[i], 16);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) po[i][c] += wb_shfl_xor(po[i][c], 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) {
+                pl[i] += wb_shfl_xor(pl[i], 32);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) po[i][c] += wb_shfl_xor(po[i][c], 32);
+            }
+            if (lane < 16) {
+                // the head's four output channels of a token = half of operand chunk h >> 1: 8 bytes per term, already split
+                unsigned char* ao = XS + (h >> 1) * 256 + lane * 16 + (h & 1) * 8;
+#pragma unroll
+                for (int i = 0; i < NQT; ++i) {
+                    const float inv = 1.f / pl[i];
+                    unsigned t[3][2];
+                    ws_split2(po[i][0] * inv, po[i][1] * inv, t[0][0], t[1][0], t[2][0]);
+                    ws_split2(po[i][2] * inv, po[i][3] * inv, t[0][1], t[1][1], t[2][1]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + i * WS_XS_TILE) = uint2{t[k][0], t[k][1]};
+                }
+                // token tile 3: column 0 = query 48, the other columns carry no attention output
+                const float inv48 = 1.f / l48;
+                unsigned t[3][2];
+                ws_split2(lane == 0 ? o48[0] * inv48 : 0.f, lane == 0 ? o48[1] * inv48 : 0.f, t[0][0], t[1][0], t[2][0]);
+                ws_split2(lane == 0 ? o48[2] * inv48 : 0.f, lane == 0 ? o48[3] * inv48 : 0.f, t[0][1], t[1][1], t[2][1]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + 3 * WS_XS_TILE) = uint2{t[k][0], t[k][1]};
+            }
+            // proj fragments: requested only now -- the phase above sits at the 128-register cap, and a spilled register there costs
+            // more than this load's latency (part of it passes in the barrier)
+            {
+                const sb8* wp = reinterpret_cast<const sb8*>(a.wprojS) + lane;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ap[ks][k] = wp[(((wave & 3) * 2 + ks) * 3 + k) * 64];
+            }
+        }
+        wb_sync();
+        WB_STAMP(3);
+
+        // ---- x1 = x + proj(ao): 4 row tiles x 4 token tiles, one per wave -------------------------------
+        {
+            // lane coordinates recomputed from an opaque copy: index expressions shared with the phases before the attention
+            // would otherwise be kept alive across it (the compiler spilled them: seven registers, each reload a scratch round trip)
+            int lane_p;
+            asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane_p) : "v"(tid));
+            const int lane = lane_p, g4 = lane_p >> 4, col = lane_p & 15;
+            auto load_b = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[3]) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g4) * 256 + col * 16);
+            };
+            const int rt = wave & 3, i = wave >> 2;
+            {
+                const sb8* w1 = reinterpret_cast<const sb8*>(a.wfc1S) + lane;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) a1[ks][k] = w1[((wave * 2 + ks) * 3 + k) * 64];
+            }
+            sb8 b0[3], b1[3];
+            load_b(XS, WS_XS_TERM, WS_XS_TILE, i, 0, b0);
+            load_b(XS, WS_XS_TERM, WS_XS_TILE, i, 1, b1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ws_mma6(ap[0], b0, acc);
+            acc = ws_mma6(ap[1], b1, acc);
+            const int row0 = rt * 16 + g4 * 4;
+            const bool carried = i == 3 && col >= 1;       // token columns 49..63: x1 = x of a pixel outside every window
+            float s1 = 0.f, s2 = 0.f, x1v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* xp = XT + (i * WB_C + row0 + r) * 16 + col;
+                const float v = carried ? *xp : *xp + acc[r] + pbproj[row0 + r];
+                *xp = v;
+                x1v[r] = v;
+                s1 += v;
+                s2 += v * v;
+            }
+            // LayerNorm2 sums over this wave's 16 rows; the four row tiles are added in a fixed order by fc1
+            s1 += wb_shfl_xor(s1, 16);
+            s2 += wb_shfl_xor(s2, 16);
+            s1 += wb_shfl_xor(s1, 32);
+            s2 += wb_shfl_xor(s2, 32);
+            if (lane < 16) {
+                S2[(rt * 64 + i * 16 + col) * 2] = s1;
+                S2[(rt * 64 + i * 16 + col) * 2 + 1] = s2;
+            }
+            wb_sync();                              // every wave has read its attention-output fragments: x1 takes their place
+            unsigned t[3][2];
+            ws_split2(x1v[0], x1v[1], t[0][0], t[1][0], t[2][0]);
+            ws_split2(x1v[2], x1v[3], t[0][1], t[1][1], t[2][1]);
+            unsigned char* d = XS + i * WS_XS_TILE + (rt * 2 + (g4 >> 1)) * 256 + col * 16 + (g4 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(d + k * WS_XS_TERM) = uint2{t[k][0], t[k][1]};
+        }
+        wb_sync();
+        WB_STAMP(4);
+    }
+
+    // ---- hidden = GELU(fc1(LayerNorm2(x1))): wave = row tile, all four token tiles ------------------
+    int lane_q;
+    asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane_q) : "v"(tid));
+    const int lane2 = lane_q, g42 = lane_q >> 4, col2 = lane_q & 15;
+    auto load_b2 = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g42) * 256 + col2 * 16);
+    };
+    const sb8* w2 = reinterpret_cast<const sb8*>(a.wfc2S) + ((long)(wave & 3) * 8 * 3) * 64 + lane2;   // fc2 fragments [rt][8 k-steps][3 terms]
+    sb8 wa[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wa[ks][k] = w2[(ks * 3 + k) * 64];
+    {
+        const int row0 = wave * 16 + g42 * 4;
+        float ss[4], bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ss[r] = psfc1[row0 + r];
+            bb[r] = pbfc1[row0 + r];
+        }
+#pragma unroll 2
+        for (int i = 0; i < 4; ++i) {
+            sb8 b0[3], b1[3];
+            load_b2(XS, WS_XS_TERM, WS_XS_TILE, i, 0, b0);
+            load_b2(XS, WS_XS_TERM, WS_XS_TILE, i, 1, b1);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float2 pp = *reinterpret_cast<const float2*>(S2 + (t * 64 + i * 16 + col2) * 2);
+                s1 += pp.x;
+                s2 += pp.y;
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ws_mma6(a1[0], b0, acc);
+            acc = ws_mma6(a1[1], b1, acc);
+            const float mu = s1 * (1.f / WB_C);
+            const float rs = __builtin_amdgcn_rsqf(fmaxf(s2 * (1.f / WB_C) - mu * mu, 0.f) + 1e-5f);
+            float hv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = gelu_f(rs * (acc[r] - mu * ss[r]) + bb[r]);
+            unsigned t[3][2];
+            ws_split2(hv[0], hv[1], t[0][0], t[1][0], t[2][0]);
+            ws_split2(hv[2], hv[3], t[0][1], t[1][1], t[2][1]);
+            unsigned char* d = HS + i * WS_HID_TILE + (wave * 2 + (g42 >> 1)) * 256 + col2 * 16 + (g42 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(d + k * WS_HID_TERM) = uint2{t[k][0], t[k][1]};
+        }
+    }
+    wb_sync();
+    { const int lane = lane2; WB_STAMP(5); }
+
+    // ---- x2 = x1 + fc2(hidden) (+ merged[t]): 4 row tiles x 4 token tiles, K = 256 = 8 k-steps ----------------------
+    {
+        const int rt = wave & 3, i = wave >> 2;
+        sb8 wb[2][3];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {                // two k-steps per round, the next round's fragments in flight
+            if (kp + 1 < 4) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const sb8 v = w2[(((kp + 1) * 2 + ks) * 3 + k) * 64];
+                        if (kp & 1) wa[ks][k] = v; else wb[ks][k] = v;
+                    }
+            }
+            sb8 b0[3], b1[3];
+            load_b2(HS, WS_HID_TERM, WS_HID_TILE, i, 2 * kp, b0);
+            load_b2(HS, WS_HID_TERM, WS_HID_TILE, i, 2 * kp + 1, b1);
+            if (kp & 1) {
+                acc = ws_mma6(wb[0], b0, acc);
+                acc = ws_mma6(wb[1], b1, acc);
+            } else {
+                acc = ws_mma6(wa[0], b0, acc);
+                acc = ws_mma6(wa[1], b1, acc);
+            }
+        }
+        const int pix = PIX[i * 16 + col2];
+        if (pix >= 0) {
+            const int row0 = rt * 16 + g42 * 4;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = XT[(i * WB_C + row0 + r) * 16 + col2] + acc[r] + pbfc2[row0 + r];
+            if (a.addres) {
+                const float4 ad = *reinterpret_cast<const float4*>(a.addres + b * a.addres_bs + (long)pix * WB_C + row0);
+                y[0] += ad.x; y[1] += ad.y; y[2] += ad.z; y[3] += ad.w;
+            }
+            *reinterpret_cast<float4*>(a.out + b * a.out_bs + (long)pix * WB_C + row0) = float4{y[0], y[1], y[2], y[3]};
+            if (a.out_nchw) {
+                float* ob = a.out_nchw + b * a.out_bs + pix;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ob[(long)(row0 + r) * HW] = y[r];
+            }
+        }
+    }
+    { const int lane = lane2; WB_STAMP(6); }
+}
+
+static int winblock_sb_launch(WinArgs a, int B, hipStream_t stream) {
+    static unsigned char raised[BDE_MAX_DEVICES];
+    BDE_HIP(raise_dynamic_lds(raised, (const void*)winblock_sb_kernel));
+    winblock_geometry(a);
+    int extra = 0;
+    if (a.ke > 15) { a.ke = 0; extra = cdiv(a.nA + a.nB, 64); }
+    hipLaunchKernelGGL(winblock_sb_kernel, dim3(a.nWin + extra, 1, B), dim3(1024), WS_END, stream, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+}  // namespace bde

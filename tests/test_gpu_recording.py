@@ -82,11 +82,14 @@ def test_attributes_that_overstate_the_columns_cannot_reach_past_them(golden):
     z, meta, rec = golden
     lying = dict(rec)
     lying['num_events'] = int(rec['num_events']) + 5000
-    lying['event_idx'] = [int(v) for v in rec['event_idx'][:-1]] + [int(rec['num_events']) + 4000]
+    # (between_frames: item i is the window that ends at image i's event_idx; there are num_imgs - 1 items)
+    lying['event_idx'] = [int(v) for v in rec['event_idx'][:-2]] + [int(rec['num_events']) + 4000] * 2
     ds = Recording(arrays=lying)
     assert ds.num_events == len(rec['ts'])
     with pytest.raises(IndexError, match='out of bounds'):
         ds.voxels([len(ds) - 1])
+    with pytest.raises(IndexError, match='out of bounds'):
+        ds[len(ds) - 1]
     ok = ds.voxels(range(len(ds) - 1))
     ref = Recording(arrays=rec).voxels(range(len(ds) - 1))
     assert torch.equal(ok, ref)

@@ -19,19 +19,27 @@ m.set_tuning('winblock', 0)
 y_split = ops.dframe_attention(m, 0, bufs)
 m.set_tuning('winblock', 1)
 print('max |winblock - split path| over 4 blocks:', float((y - y_split).abs().max()))
-L.bde_profile_reset(m._h, 1)
-for _ in range(25):
-    ops.dframe_attention(m, 0, bufs)
-torch.cuda.synchronize()
-ms, cnt = C.c_double(), C.c_int64()
-L.bde_profile_get(m._h, b'winblock0', C.byref(ms), C.byref(cnt))
-print(f'winblock0: {cnt.value} launches, {ms.value / cnt.value * 1e3:.2f} us each (HIP events, eager)')
-L.bde_profile_reset(m._h, 0)
+for sb in (0, 1, 0, 1):
+    m.set_tuning('winblock_sb', sb)
+    ysb = ops.dframe_attention(m, 0, bufs)
+    L.bde_profile_reset(m._h, 1)
+    for _ in range(25):
+        ops.dframe_attention(m, 0, bufs)
+    torch.cuda.synchronize()
+    ms, cnt = C.c_double(), C.c_int64()
+    L.bde_profile_get(m._h, b'winblock0', C.byref(ms), C.byref(cnt))
+    print(f'winblock_sb={sb}: {cnt.value} launches, {ms.value / cnt.value * 1e3:.2f} us each (HIP events, eager); '
+          f'max |y - split path| {float((ysb - y_split).abs().max()):.3e}')
+    L.bde_profile_reset(m._h, 0)
 L.bde_debug_token_stamps(m._h, None, 0)
-ops.dframe_attention(m, 0, bufs, 0, 1)
-torch.cuda.synchronize()
-out = (C.c_int64 * 2048)()
-L.bde_debug_token_stamps(m._h, out, 2048)
-a = np.array(out[:], dtype=np.int64).reshape(64, 4, 8)
-d = a[:, :, 1:8] - a[:, :, 0:7]
-print('phase cycles median over (block, wave):', np.median(d.reshape(-1, 7), axis=0), ' total', np.median(a[:, :, 6] - a[:, :, 0]))
+for sb in (0, 1):
+    m.set_tuning('winblock_sb', sb)
+    ops.dframe_attention(m, 0, bufs, 0, 1)
+    torch.cuda.synchronize()
+    out = (C.c_int64 * 2048)()
+    L.bde_debug_token_stamps(m._h, out, 2048)
+    a = np.array(out[:], dtype=np.int64).reshape(64, 4, 8)
+    d = a[:, :, 1:7] - a[:, :, 0:6]
+    print(f'winblock_sb={sb} phase cycles (gather, qkv, attention, proj, fc1, fc2), median over (block, wave):',
+          np.median(d.reshape(-1, 6), axis=0), ' total', np.median(a[:, :, 6] - a[:, :, 0]),
+          ' score loop (stamp 7 - stamp 2)', np.median(a[:, :, 7] - a[:, :, 2]))
