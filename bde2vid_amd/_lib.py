@@ -17,7 +17,9 @@ class BdeConfig(C.Structure):
     _fields_ = [('num_bins', C.c_int32), ('basechannels', C.c_int32), ('num_encoders', C.c_int32),
                 ('ks', C.c_int32), ('num_heads', C.c_int32), ('frame_num', C.c_int32),
                 ('q_idx', C.c_int32), ('activation', C.c_int32),
-                ('depths', C.c_int32 * MAX_LEVELS), ('buffer_index', C.c_int32 * MAX_FRAMES)]
+                ('depths', C.c_int32 * MAX_LEVELS), ('buffer_index', C.c_int32 * MAX_FRAMES),
+                ('recurrent_type', C.c_int32), ('use_rc', C.c_int32), ('skip_concat', C.c_int32),
+                ('norm', C.c_int32), ('num_res_blocks', C.c_int32)]
 
 
 _P = C.c_void_p
@@ -108,4 +110,9 @@ def make_config(cfg) -> BdeConfig:
         c.depths[i] = int(d)
     for i, b in enumerate(cfg.buffer_index):
         c.buffer_index[i] = int(b)
+    c.recurrent_type = 1 if cfg.recurrent_block_type == 'convgru' else 0
+    c.use_rc = 1 if cfg.useRC else 0
+    c.skip_concat = 1 if cfg.skip_type == 'concat' else 0
+    c.norm = cfg.norm_kind
+    c.num_res_blocks = int(cfg.num_res_blocks)
     return c

@@ -43,17 +43,29 @@ class GeneratorConfig:
     def enc_out(self, l: int) -> int:
         return self.basechannels * 2 ** (l + 1)
 
+    @property
+    def norm_kind(self) -> int:
+        """0 = no norm layer, 1 = BatchNorm2d, 2 = InstanceNorm2d(track_running_stats=True) (submodules.py:96-103); any other
+        string builds a ConvLayer without a norm layer, exactly as None does."""
+        return {'BN': 1, 'IN': 2}.get(self.norm, 0)
+
+    @property
+    def bottleneck(self) -> bool:
+        """depths[-1] == 0: the last level runs num_res_blocks ResidualBlockNoBN on buffer slot 0 instead of attention
+        (V5.py:77-80, 262-282)."""
+        return self.depths[-1] == 0
+
     def validate(self) -> None:
-        """Reject configurations outside the hot path (last row)."""
+        """Reject what the reference itself cannot run or what the kernels are not built for: everything else the
+        constructor of the reference accepts (V5.py:19-98) is built -- ConvLSTM / ConvGRU / plain encoders, skip sum / concat,
+        norm None / BN / IN (eval mode), attention or the residual-block bottleneck on the last level."""
         bad = []
-        if self.norm not in (None, 'none'):
-            bad.append(f'norm={self.norm!r} (only None is on the BDE2VID path)')
-        if self.recurrent_block_type != 'convlstm':
-            bad.append(f'recurrent_block_type={self.recurrent_block_type!r}')
-        if not self.useRC:
-            bad.append('useRC=False')
-        if self.skip_type != 'sum':
-            bad.append(f'skip_type={self.skip_type!r}')
+        if self.norm not in (None, 'none', 'BN', 'IN'):
+            bad.append(f'norm={self.norm!r} (None, "BN" or "IN")')
+        if self.recurrent_block_type not in ('convlstm', 'convgru'):
+            bad.append(f'recurrent_block_type={self.recurrent_block_type!r} (the reference asserts convlstm | convgru)')
+        if self.skip_type not in ('sum', 'concat'):
+            bad.append(f'skip_type={self.skip_type!r} ("no_skip" hands a list to the decoder in the reference and raises there)')
         if self.activation not in ('Sigmoid', 'Identity'):
             bad.append(f'activation={self.activation!r}')
         if self.act_net not in ('default', 'ReLU'):
@@ -66,8 +78,8 @@ class GeneratorConfig:
             bad.append(f'num_output_channels={self.num_output_channels}')
         if len(self.depths) != self.num_encoders:
             bad.append('len(depths) != num_encoders')
-        if self.depths[-1] == 0:
-            bad.append('depths[-1]==0 (ResidualBlockNoBN bottleneck)')
+        if self.bottleneck and self.num_res_blocks < 0:
+            bad.append(f'num_res_blocks={self.num_res_blocks}')
         if tuple(self.window_size) != (7, 7):
             bad.append(f'window_size={self.window_size} (kernels are built for 7x7)')
         if self.ks not in (3, 5):

@@ -256,6 +256,54 @@ __global__ __launch_bounds__(256) void pred_kernel(const float* __restrict__ x, 
     }
 }
 
+// ConvGRU step, element-wise halves (submodules.py:368-375).  gx = x-parts of update | reset | out incl. biases, [3C][HW] per
+// (direction, frame); gh_ur = h-parts of update | reset, [2][B][2C][HW]; gh_o = h-part of the candidate, [2][B][C][HW]; both
+// nullptr at the first step of a sweep (h = 0).  Plain expf / tanhf: a correctness path, not a tuned one.
+struct GruArgs {
+    const float *gx, *gh_ur, *gh_o, *hprev;
+    float *ubuf, *hr, *hout;
+    long gx_gs, gx_ns, hp_gs, hp_ns, ho_gs, ho_ns;
+    int C, B;
+    long HW;
+};
+__global__ __launch_bounds__(256) void gru_gate_kernel(const GruArgs a) {
+    const long per = (long)a.C * a.HW, total = 2L * a.B * per;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long z = i / per, e = i - z * per;
+        const int g = (int)(z / a.B), n = (int)(z - (long)g * a.B);
+        const float* gx = a.gx + g * a.gx_gs + n * a.gx_ns;
+        float vu = gx[e], vr = gx[per + e];
+        if (a.gh_ur) {
+            const float* gh = a.gh_ur + z * 2 * per;
+            vu += gh[e];
+            vr += gh[per + e];
+        }
+        const float u = 1.f / (1.f + expf(-vu)), r = 1.f / (1.f + expf(-vr));
+        a.ubuf[i] = u;
+        a.hr[i] = a.hprev ? a.hprev[g * a.hp_gs + n * a.hp_ns + e] * r : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void gru_out_kernel(const GruArgs a) {
+    const long per = (long)a.C * a.HW, total = 2L * a.B * per;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long z = i / per, e = i - z * per;
+        const int g = (int)(z / a.B), n = (int)(z - (long)g * a.B);
+        float vo = a.gx[g * a.gx_gs + n * a.gx_ns + 2 * per + e];
+        if (a.gh_o) vo += a.gh_o[i];
+        const float u = a.ubuf[i], o = tanhf(vo);
+        const float hp = a.hprev ? a.hprev[g * a.hp_gs + n * a.hp_ns + e] : 0.f;
+        a.hout[g * a.ho_gs + n * a.ho_ns + e] = hp * (1.f - u) + o * u;      // submodules.py:374
+    }
+}
+// out[n] = cat(a[n], b[n]) along channels: two strided copies (skip_concat, V5.py:285-286)
+static int concat_channels(const float* a, const float* b, float* out, long N, long ca_hw, long cb_hw, hipStream_t s) {
+    BDE_HIP(hipMemcpy2DAsync(out, sizeof(float) * (ca_hw + cb_hw), a, sizeof(float) * ca_hw, sizeof(float) * ca_hw, (size_t)N,
+                             hipMemcpyDeviceToDevice, s));
+    BDE_HIP(hipMemcpy2DAsync(out + ca_hw, sizeof(float) * (ca_hw + cb_hw), b, sizeof(float) * cb_hw, sizeof(float) * cb_hw, (size_t)N,
+                             hipMemcpyDeviceToDevice, s));
+    return BDE_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // packed layers
 // ------------------------------------------------------------------------------------------
@@ -526,6 +574,9 @@ struct Workspace {
     float* sb = nullptr;          // split-bf16 image of the input of the convolution in flight (conv_sb.h)
     float* sb2 = nullptr;         // split-bf16 encoder output of a level, written by the encoder conv's epilogue for its gate conv
     long sb2_bytes = 0;
+    std::vector<float*> gur, ghr, gou, gub;   // ConvGRU per level: h-parts of update | reset, h * reset, h-part of the candidate, update gate
+    float *cat = nullptr, *fuse = nullptr;    // skip_concat: cat(skip, x) and the 1x1 fusion's output
+    float *rbA = nullptr, *rbX[2] = {nullptr, nullptr}, *zero_l = nullptr;   // bottleneck: conv1 output, block outputs, a zero frame
     std::vector<float*> hsb, ghb; // per level: hidden state as SB16, two buffers [2][2 dirs][B][C16][hw] / h-part of the gates [2][B][4C][hw]
     long sb_bytes = 0;
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
@@ -554,6 +605,10 @@ struct bde_model {
     PackedLayer head, pred_dummy;
     std::vector<PackedLayer> enc, gx, lstm, lstm8, dec;   // enc/gx/lstm: G=2 (fwd,bwd); lstm8 = the 8-channel-workgroup packing
     std::vector<PackedLayer> lstm_sb;                     // h-part of the gates, split-bf16 packing only (conv_sb.h)
+    std::vector<PackedLayer> gru_ur, gru_o;               // ConvGRU: h-parts of update | reset and of the candidate (G = 2)
+    std::vector<PackedLayer> dec_fuse;                    // skip_concat: 1x1 fusion conv in front of decoder j
+    PackedLayer pred_fuse;                                // ... and in front of predI
+    std::vector<PackedLayer> rb1, rb2;                    // ResidualBlockNoBN bottleneck: conv1 / conv2 of block k
     std::vector<AttnLevel> attn;
     long predw_off = -1, predb_off = -1, zero_off = -1;
     // Workspace slots: slot 0 always; with pipeline depth 2 consecutive forward calls alternate between
@@ -655,6 +710,46 @@ static int get_raw(bde_model* m, const std::string& key, std::vector<int64_t> sh
     return BDE_OK;
 }
 
+static const float* get_raw_opt(bde_model* m, const std::string& key, int64_t n) {
+    auto it = m->raw.find(GP + key);
+    if (it == m->raw.end()) return nullptr;
+    int64_t have = 1;
+    for (auto v : it->second.first) have *= v;
+    return have == n ? it->second.second.data() : nullptr;
+}
+
+// ConvLayer / UpsampleConvLayer (submodules.py:85-147) as ONE dense convolution: conv2d (no bias under BN, :91) followed by
+// BatchNorm2d or InstanceNorm2d(track_running_stats=True) in eval mode (:96-109) is the affine y -> (y - mean) * s + beta with
+// s = gamma / sqrt(var + eps) per output channel, folded into the weights and the bias (fp64).
+static int dense_conv(bde_model* m, const std::string& wkey, const std::string& bkey, int rows, int cin_total,
+                      int ci_off, int cin, int ks, bool with_bias, DenseLayer* d);
+static int dense_convlayer(bde_model* m, const std::string& prefix, int rows, int cin, int ks, DenseLayer* d) {
+    const int norm = m->cfg.norm;
+    const float* w;
+    BDE_TRY(get_raw(m, prefix + "conv2d.weight", {rows, cin, ks, ks}, &w));
+    const float* b = nullptr;
+    if (norm != 1) BDE_TRY(get_raw(m, prefix + "conv2d.bias", {rows}, &b));
+    d->rows = rows; d->Cin = cin; d->KS = ks;
+    d->w.assign(w, w + (size_t)rows * cin * ks * ks);
+    d->bias.assign(rows, 0.f);
+    if (b) std::copy(b, b + rows, d->bias.begin());
+    if (norm == 0) return BDE_OK;
+    const float *mean, *var, *gamma = nullptr, *beta = nullptr;
+    BDE_TRY(get_raw(m, prefix + "norm_layer.running_mean", {rows}, &mean));
+    BDE_TRY(get_raw(m, prefix + "norm_layer.running_var", {rows}, &var));
+    if (norm == 1) {
+        BDE_TRY(get_raw(m, prefix + "norm_layer.weight", {rows}, &gamma));
+        BDE_TRY(get_raw(m, prefix + "norm_layer.bias", {rows}, &beta));
+    }
+    const size_t per_row = (size_t)cin * ks * ks;
+    for (int r = 0; r < rows; ++r) {
+        const double sc = (gamma ? (double)gamma[r] : 1.0) / std::sqrt((double)var[r] + 1e-5);
+        for (size_t i = 0; i < per_row; ++i) d->w[r * per_row + i] = (float)((double)d->w[r * per_row + i] * sc);
+        d->bias[r] = (float)(((double)d->bias[r] - (double)mean[r]) * sc + (beta ? (double)beta[r] : 0.0));
+    }
+    return BDE_OK;
+}
+
 static int dense_conv(bde_model* m, const std::string& wkey, const std::string& bkey, int rows, int cin_total,
                       int ci_off, int cin, int ks, bool with_bias, DenseLayer* d) {
     const float *w, *b;
@@ -702,27 +797,65 @@ static int build_packed(bde_model* m) {
     m->lstm_sb.assign(L, PackedLayer());
     m->dec.assign(L, PackedLayer());
     m->attn.assign(L, AttnLevel());
+    m->gru_ur.assign(L, PackedLayer());
+    m->gru_o.assign(L, PackedLayer());
+    m->dec_fuse.assign(L, PackedLayer());
+    m->rb1.clear();
+    m->rb2.clear();
     {
         DenseLayer d;
-        BDE_TRY(dense_conv(m, "head.conv2d.weight", "head.conv2d.bias", bc, c.num_bins, 0, c.num_bins, ks, true, &d));
+        BDE_TRY(dense_convlayer(m, "head.", bc, c.num_bins, ks, &d));
         m->head = pack_layer(ar, {&d}, false);
     }
     const char* dirs[2] = {"forward_encoder", "backward_encoder"};
     for (int l = 0; l < L; ++l) {
         const int ci = m->cin(l), co = m->cout(l);
-        DenseLayer e[2], gxd[2], gh[2];
+        DenseLayer e[2];
+        for (int d = 0; d < 2; ++d) {
+            // RecurrentConv.conv (submodules.py:186-187) or, with useRC = False, the encoder itself (V5.py:256-258)
+            std::string p = std::string(dirs[d]) + "." + std::to_string(l) + (c.use_rc ? ".conv." : ".");
+            BDE_TRY(dense_convlayer(m, p, co, ci, ks, &e[d]));
+        }
+        m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, false);
+        pack_split_bf16(ar, m->enc[l], {&e[0], &e[1]});
+        if (!c.use_rc) continue;
+        if (c.recurrent_type == 1) {
+            // ConvGRU (submodules.py:348-376): three 3x3 convolutions on cat(x, h) / cat(x, h * reset); in-channel order [x | h].
+            // x-parts (rows update | reset | out, with the biases) batched over T like the LSTM's; h-parts per step.
+            DenseLayer gxd[2], gur[2], go[2];
+            const char* gates[3] = {"update_gate", "reset_gate", "out_gate"};
+            for (int d = 0; d < 2; ++d) {
+                std::string p = std::string(dirs[d]) + "." + std::to_string(l) + ".recurrent_block.";
+                gxd[d].rows = 3 * co; gxd[d].Cin = co; gxd[d].KS = 3;
+                gur[d].rows = 2 * co; gur[d].Cin = co; gur[d].KS = 3;
+                go[d].rows = co; go[d].Cin = co; go[d].KS = 3;
+                for (int q = 0; q < 3; ++q) {
+                    DenseLayer xs, hs;
+                    BDE_TRY(dense_conv(m, p + gates[q] + ".weight", p + gates[q] + ".bias", co, 2 * co, 0, co, 3, true, &xs));
+                    BDE_TRY(dense_conv(m, p + gates[q] + ".weight", p + gates[q] + ".bias", co, 2 * co, co, co, 3, false, &hs));
+                    gxd[d].w.insert(gxd[d].w.end(), xs.w.begin(), xs.w.end());
+                    gxd[d].bias.insert(gxd[d].bias.end(), xs.bias.begin(), xs.bias.end());
+                    DenseLayer& hd = q < 2 ? gur[d] : go[d];
+                    hd.w.insert(hd.w.end(), hs.w.begin(), hs.w.end());
+                    hd.bias.insert(hd.bias.end(), hs.bias.begin(), hs.bias.end());
+                }
+            }
+            m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, false);
+            pack_split_bf16(ar, m->gx[l], {&gxd[0], &gxd[1]});
+            m->gru_ur[l] = pack_layer(ar, {&gur[0], &gur[1]}, false);
+            m->gru_o[l] = pack_layer(ar, {&go[0], &go[1]}, false);
+            continue;
+        }
+        DenseLayer gxd[2], gh[2];
         for (int d = 0; d < 2; ++d) {
             std::string p = std::string(dirs[d]) + "." + std::to_string(l) + ".";
-            BDE_TRY(dense_conv(m, p + "conv.conv2d.weight", p + "conv.conv2d.bias", co, ci, 0, ci, ks, true, &e[d]));
             // Gates weight in-channel order is [x | h] (submodules.py:316)
             BDE_TRY(dense_conv(m, p + "recurrent_block.Gates.weight", p + "recurrent_block.Gates.bias", 4 * co, 2 * co, 0,
                                co, 3, true, &gxd[d]));
             BDE_TRY(dense_conv(m, p + "recurrent_block.Gates.weight", p + "recurrent_block.Gates.bias", 4 * co, 2 * co, co,
                                co, 3, false, &gh[d]));
         }
-        m->enc[l] = pack_layer(ar, {&e[0], &e[1]}, false);
         m->gx[l] = pack_layer(ar, {&gxd[0], &gxd[1]}, false);
-        pack_split_bf16(ar, m->enc[l], {&e[0], &e[1]});
         pack_split_bf16(ar, m->gx[l], {&gxd[0], &gxd[1]});
         m->lstm[l] = pack_lstm16(ar, {&gh[0], &gh[1]});
         m->lstm8[l] = pack_lstm8(ar, {&gh[0], &gh[1]});
@@ -730,6 +863,18 @@ static int build_packed(bde_model* m) {
             PackedLayer& ps = m->lstm_sb[l];
             ps.Cin = co; ps.Cout = 4 * co; ps.KS = 3; ps.G = 2;
             pack_split_bf16(ar, ps, {&gh[0], &gh[1]});
+        }
+    }
+    if (c.depths[L - 1] == 0) {
+        // Sequential(ParseLayer, ResidualBlockNoBN x num_res_blocks) in place of the last level's attention (V5.py:77-80)
+        const int C = m->cout(L - 1);
+        for (int k = 0; k < c.num_res_blocks; ++k) {
+            std::string p = "feat_attns." + std::to_string(L - 1) + "." + std::to_string(1 + k) + ".";
+            DenseLayer c1, c2;
+            BDE_TRY(dense_conv(m, p + "conv1.weight", p + "conv1.bias", C, C, 0, C, 3, true, &c1));
+            BDE_TRY(dense_conv(m, p + "conv2.weight", p + "conv2.bias", C, C, 0, C, 3, true, &c2));
+            m->rb1.push_back(pack_layer(ar, {&c1}, false));
+            m->rb2.push_back(pack_layer(ar, {&c2}, false));
         }
     }
     const int D = c.frame_num, heads = c.num_heads;
@@ -870,10 +1015,20 @@ static int build_packed(bde_model* m) {
     for (int j = 0; j < L; ++j) {
         const int cin = m->cout(L - 1 - j), cout = m->cin(L - 1 - j);
         DenseLayer d;
-        std::string p = "decoders." + std::to_string(j) + ".1.conv2d.";
-        BDE_TRY(dense_conv(m, p + "weight", p + "bias", cout, cin, 0, cin, ks, true, &d));
+        BDE_TRY(dense_convlayer(m, "decoders." + std::to_string(j) + ".1.", cout, cin, ks, &d));
         m->dec[j] = pack_layer(ar, {&d}, false);
         pack_split_bf16(ar, m->dec[j], {&d});
+        if (c.skip_concat) {                        // 1x1 fusion of cat(skip, x) (V5.py:86-89)
+            DenseLayer f;
+            std::string p = "decoders." + std::to_string(j) + ".0.";
+            BDE_TRY(dense_conv(m, p + "weight", p + "bias", cin, 2 * cin, 0, 2 * cin, 1, true, &f));
+            m->dec_fuse[j] = pack_layer(ar, {&f}, false);
+        }
+    }
+    if (c.skip_concat) {                            // V5.py:92-93
+        DenseLayer f;
+        BDE_TRY(dense_conv(m, "predI.0.weight", "predI.0.bias", bc, 2 * bc, 0, 2 * bc, 1, true, &f));
+        m->pred_fuse = pack_layer(ar, {&f}, false);
     }
     {
         const float *w, *b;
@@ -1056,6 +1211,8 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     BDE_TRY(ws_alloc(ws, &ws.out, TB * H * W));
     ws.xenc.assign(L, nullptr); ws.gx.assign(L, nullptr); ws.hseq.assign(L, nullptr); ws.cst.assign(L, nullptr);
     ws.hsb.assign(L, nullptr); ws.ghb.assign(L, nullptr);
+    ws.gur.assign(L, nullptr); ws.ghr.assign(L, nullptr); ws.gou.assign(L, nullptr); ws.gub.assign(L, nullptr);
+    const bool gru = c.use_rc && c.recurrent_type == 1;
     ws.merged.assign(L, nullptr); ws.mergedT.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
     long max_attn = 0;
     for (int l = 0; l < L; ++l) {
@@ -1065,7 +1222,13 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.gx[l], 2 * TB * 4 * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.hseq[l], 2 * TB * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.cst[l], 2 * (long)B * C * hw));
-        if (lstm_sb_ok(m, l, B, H >> (l + 1), W >> (l + 1))) {
+        if (gru) {
+            BDE_TRY(ws_alloc(ws, &ws.gur[l], 2L * B * 2 * C * hw));
+            BDE_TRY(ws_alloc(ws, &ws.ghr[l], 2L * B * C * hw));
+            BDE_TRY(ws_alloc(ws, &ws.gou[l], 2L * B * C * hw));
+            BDE_TRY(ws_alloc(ws, &ws.gub[l], 2L * B * C * hw));
+        }
+        if (!gru && c.use_rc && lstm_sb_ok(m, l, B, H >> (l + 1), W >> (l + 1))) {
             BDE_TRY(ws_alloc(ws, &ws.hsb[l], 2 * split_bf16_bytes(2L * B, (int)C, hw) / 4 + 4));
             BDE_TRY(ws_alloc(ws, &ws.ghb[l], 2L * B * 4 * C * hw));
         }
@@ -1092,6 +1255,21 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.dec[j], TB * m->cin(l) * (long)(H >> l) * (W >> l)));
     }
     BDE_TRY(ws_alloc(ws, &ws.up, TB * m->cout(0) * (long)H * W));   // dec L-1: cout(0) channels at full resolution
+    if (c.skip_concat) {
+        // largest cat(skip, x): decoder inputs 2 * cout(l) at level l, predI input 2 * basechannels at full resolution
+        long mc = TB * 2 * c.basechannels * (long)H * W;
+        for (int l = 0; l < L; ++l) mc = std::max(mc, TB * 2 * m->cout(l) * (long)(H >> (l + 1)) * (W >> (l + 1)));
+        BDE_TRY(ws_alloc(ws, &ws.cat, mc));
+        BDE_TRY(ws_alloc(ws, &ws.fuse, mc / 2));
+    }
+    if (c.depths[L - 1] == 0) {
+        const long n = (long)B * m->cout(L - 1) * (long)(H >> L) * (W >> L);
+        BDE_TRY(ws_alloc(ws, &ws.rbA, n));
+        BDE_TRY(ws_alloc(ws, &ws.rbX[0], n));
+        BDE_TRY(ws_alloc(ws, &ws.rbX[1], n));
+        BDE_TRY(ws_alloc(ws, &ws.zero_l, n));
+        BDE_HIP(hipMemset(ws.zero_l, 0, sizeof(float) * n));
+    }
     {
         // split-bf16 image of one convolution's input (6 B per element, channels padded to 16): the largest of the
         // encoder inputs, gate-conv inputs (both directions) and upsampled decoder inputs
@@ -1144,6 +1322,12 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     e.act = ACT_RELU;
     e.in_gs = 0;
     e.out_gs = TB * C * hw;
+    if (!m->cfg.use_rc) {
+        // bare ConvLayer encoders (V5.py:256-258): the convolution's output IS the level's feature sequence
+        e.out = ws.hseq[l] + (long)f0 * C * hw;
+        ProfScope ps(m, pname("enc_conv", l), s);
+        return run_conv(m, e, s);
+    }
     // the gate convolution reads its input as SB16 (conv_sb.h): the encoder conv's epilogue then writes that image directly
     // (6 B per element) and the fp32 planes + their conversion pass are skipped
     const long sb_fs = (long)cdiv(C, 16) * hw * SB_PIX_BYTES / 4;         // floats of one SB16 frame
@@ -1158,7 +1342,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     ConvCall gxc;
     gxc.pl = &m->gx[l];
     gxc.in = ws.xenc[l] + (long)f0 * C * hw;
-    gxc.out = ws.gx[l] + (long)f0 * 4 * C * hw;
+    gxc.out = ws.gx[l] + (long)f0 * m->gx[l].Cout * hw;             // rows: 4C (ConvLSTM gates) or 3C (ConvGRU)
     gxc.N = nf;
     gxc.Hs = h;
     gxc.Ws = w;
@@ -1241,12 +1425,69 @@ static int run_recurrent_steps_sb(bde_model* m, int l, int T, int B, int h, int 
     return BDE_OK;
 }
 
+// ConvGRU sweep of a level, both directions per launch (submodules.py:358-376; RecurrentConv.forward :191-195 returns the
+// state itself).  Per step: h-parts of update | reset (one 3x3 convolution, 2C rows), gates + h * reset, h-part of the
+// candidate on h * reset, blend.  The x-parts sit in ws.gx[l] as [2][TB][3C][hw] (update | reset | out).
+static int run_gru_steps(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
+    Workspace& ws = m->W();
+    const int C = m->cout(l);
+    const long TB = (long)T * B, hw = (long)h * w;
+    float* hs = ws.hseq[l];
+    const long dstride = TB * C * hw, fs = (long)B * C * hw;
+    const long total = 2L * B * C * hw;
+    const unsigned blocks = (unsigned)std::min<long>(cdivl(total, 256), 4096);
+    for (int st = 0; st < T; ++st) {
+        const int tf = st, tb = T - 1 - st;
+        ProfScope ps(m, pname("gru", l), s);
+        const float* hprev_f = hs + (long)(tf - 1) * fs;
+        const float* hprev_b = hs + dstride + (long)(tb + 1) * fs;
+        GruArgs g;
+        memset(&g, 0, sizeof g);
+        g.gx = ws.gx[l] + (long)tf * B * 3 * C * hw;
+        g.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 3 * C * hw) - g.gx;
+        g.gx_ns = 3L * C * hw;
+        g.ubuf = ws.gub[l];
+        g.hr = ws.ghr[l];
+        g.hout = hs + (long)tf * fs;
+        g.ho_gs = (hs + dstride + (long)tb * fs) - g.hout;
+        g.ho_ns = (long)C * hw;
+        g.C = C; g.B = B; g.HW = hw;
+        if (st > 0) {
+            g.hprev = hprev_f;
+            g.hp_gs = hprev_b - hprev_f;
+            g.hp_ns = (long)C * hw;
+            ConvCall ur;
+            ur.pl = &m->gru_ur[l];
+            ur.in = hprev_f; ur.in_gs = hprev_b - hprev_f;
+            ur.out = ws.gur[l]; ur.out_gs = (long)B * 2 * C * hw;
+            ur.N = B; ur.Hs = h; ur.Ws = w;
+            BDE_TRY(run_conv(m, ur, s));
+            g.gh_ur = ws.gur[l];
+        }
+        hipLaunchKernelGGL(gru_gate_kernel, dim3(blocks), dim3(256), 0, s, g);
+        if (st > 0) {
+            ConvCall oc;
+            oc.pl = &m->gru_o[l];
+            oc.in = ws.ghr[l]; oc.in_gs = (long)B * C * hw;
+            oc.out = ws.gou[l]; oc.out_gs = (long)B * C * hw;
+            oc.N = B; oc.Hs = h; oc.Ws = w;
+            BDE_TRY(run_conv(m, oc, s));
+            g.gh_o = ws.gou[l];
+        }
+        hipLaunchKernelGGL(gru_out_kernel, dim3(blocks), dim3(256), 0, s, g);
+        BDE_HIP(hipGetLastError());
+    }
+    return BDE_OK;
+}
+
 static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int B, int H, int W, hipStream_t s,
                                bool enc_done = false) {
     Workspace& ws = m->W();
     const int C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
     if (!enc_done && !(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
+    if (!m->cfg.use_rc) return BDE_OK;
+    if (m->cfg.recurrent_type == 1) return run_gru_steps(m, l, T, B, h, w, s);
     if (!(m->debug_skip & 4) && ws.hsb[l] != nullptr) return run_recurrent_steps_sb(m, l, T, B, h, w, s);
     // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
     const PackedLayer& pl = m->lstm[l];
@@ -1634,7 +1875,48 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
 // UpsampleConvLayer of decoder j on N frames [Cin][Hs][Ws] (+ skip): upsample kernel, then a plain conv.
 // predI + the output activation ride in the conv's epilogue when one workgroup holds every output channel of a pixel
 // (Cout <= 64: the 32 channels of the canonical last decoder are one MFMA row tile)
-static bool pred_fusable(const bde_model* m) { return m->cfg.basechannels <= 64 && m->fuse_pred; }
+static bool pred_fusable(const bde_model* m) { return m->cfg.basechannels <= 64 && m->fuse_pred && !m->cfg.skip_concat; }
+
+// skip_concat in front of a decoder or of predI (V5.py:285-286, 86-93): y = Conv1x1(cat(first, second)) on N frames of
+// [C][hw] each -> ws.fuse
+static int run_concat_fuse(bde_model* m, const PackedLayer& pl, const float* first, const float* second, int N, int C, long hw,
+                           hipStream_t s) {
+    Workspace& ws = m->W();
+    BDE_TRY(concat_channels(first, second, ws.cat, N, (long)C * hw, (long)C * hw, s));
+    return run_pw(m, &pl, ws.cat, ws.fuse, N, hw, ACT_NONE, nullptr, nullptr, 0, 0, 0, s);
+}
+
+// The last level without attention (depths[-1] == 0): Sequential(ParseLayer, ResidualBlockNoBN x n) on the frame buffer
+// (V5.py:77-80, 151-169).  ParseLayer takes buffer SLOT 0 (:281-282), i.e. the frame at offset buffer_index[0] -- refined
+// already when that offset is negative, still unrefined when it is not, zeros outside the sequence -- and the result is added
+// to merged[t] in place: sequential in t like the attention.
+static int run_bottleneck_level(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
+    const bde_config& c = m->cfg;
+    Workspace& ws = m->W();
+    const int C = m->cout(l), nb = c.num_res_blocks;
+    const long fs = (long)B * C * h * w;
+    for (int t = 0; t < T; ++t) {
+        ProfScope ps(m, pname("bottleneck", l), s);
+        const int f = t + c.buffer_index[0];
+        float* mt = ws.merged[l] + (long)t * fs;
+        const float* x = (f < 0 || f >= T) ? ws.zero_l : ws.merged[l] + (long)f * fs;
+        if (nb == 0) { BDE_TRY(add2(x, mt, mt, fs, s)); continue; }
+        for (int k = 0; k < nb; ++k) {
+            ConvCall c1;                                     // relu(conv1(x))
+            c1.pl = &m->rb1[k]; c1.in = x; c1.out = ws.rbA; c1.N = B; c1.Hs = h; c1.Ws = w; c1.act = ACT_RELU;
+            BDE_TRY(run_conv(m, c1, s));
+            const bool last = k == nb - 1;
+            ConvCall c2;                                     // x + conv2(.)   (+ merged[t] after the last block, V5.py:166)
+            c2.pl = &m->rb2[k]; c2.in = ws.rbA; c2.N = B; c2.Hs = h; c2.Ws = w; c2.act = ACT_NONE;
+            c2.res1 = x;
+            c2.res2 = last ? mt : nullptr;
+            c2.out = last ? mt : ws.rbX[k & 1];
+            BDE_TRY(run_conv(m, c2, s));
+            x = c2.out;
+        }
+    }
+    return BDE_OK;
+}
 
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
                        hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr) {
@@ -1791,7 +2073,13 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
             const long out_fs = (long)mm->cin(l) * (H_ >> l) * (W_ >> l);
             ProfScope ps(mm, "decoder", st);
             const bool fuse = (j == L_ - 1) && pred_fusable(mm);       // V5.py:195-197 in the last conv's epilogue
-            BDE_TRY(run_decoder(mm, j, x, w.merged[l] + (long)f0 * in_fs, w.dec[j] + (long)f0 * out_fs, nf,
+            const float* skip = w.merged[l] + (long)f0 * in_fs;
+            if (mm->cfg.skip_concat) {                                 // decoder = Sequential(1x1 fusion, UpsampleConvLayer)
+                BDE_TRY(run_concat_fuse(mm, mm->dec_fuse[j], skip, x, nf, mm->cout(l), (long)(H_ >> (l + 1)) * (W_ >> (l + 1)), st));
+                x = w.fuse;
+                skip = nullptr;
+            }
+            BDE_TRY(run_decoder(mm, j, x, skip, w.dec[j] + (long)f0 * out_fs, nf,
                                 H_ >> (l + 1), W_ >> (l + 1), st,
                                 fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
                                 fuse ? w.out + (long)f0 * H_ * W_ : nullptr));
@@ -1801,15 +2089,22 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         const long total = (long)nf * H_ * W_;
         long blocks = std::min<long>(cdivl(total, 256), 4096);
         ProfScope ps(mm, "pred", st);
+        const float* hd = w.head + (long)f0 * mm->cfg.basechannels * H_ * W_;
+        if (mm->cfg.skip_concat) {                                     // predI = Sequential(1x1 fusion of cat(x, head), 1x1)
+            BDE_TRY(run_concat_fuse(mm, mm->pred_fuse, x, hd, nf, mm->cfg.basechannels, (long)H_ * W_, st));
+            x = w.fuse;
+            hd = nullptr;
+        }
         hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x,
-                           w.head + (long)f0 * mm->cfg.basechannels * H_ * W_, mm->P(mm->predw_off),
+                           hd, mm->P(mm->predw_off),
                            mm->P(mm->predb_off), w.out + (long)f0 * H_ * W_, mm->cfg.basechannels, (long)H_ * W_, total,
                            mm->cfg.activation);
         BDE_HIP(hipGetLastError());
         return BDE_OK;
     };
     static auto decode_fn = decode_frames;
-    const bool overlap = m->overlap != 0 && m->pipeline < 2;   // the side stream and its events are per model, not per slot
+    const bool plain_flags = c.use_rc && c.recurrent_type == 0 && !c.skip_concat && c.depths[c.num_encoders - 1] > 0;
+    const bool overlap = m->overlap != 0 && m->pipeline < 2 && plain_flags;   // the side stream and its events are per model, not per slot
     if (overlap && !m->side) {
         int lo = 0, hi = 0;                               // lowest priority: the chain on the main stream goes first
         BDE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1855,6 +2150,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
                 if (l == L - 1) decoded = true; else enc_done = true;
             }
         }
+        if (l == L - 1 && c.depths[l] == 0) BDE_TRY(run_bottleneck_level(m, l, T, B, h, w, s));
         target = ws.merged[l];
     }
     if (!decoded && !(m->debug_skip & 8)) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s));
@@ -1870,7 +2166,11 @@ static int validate_config(const bde_config* c) {
     BDE_REQUIRE(c->q_idx >= 0 && c->q_idx < c->frame_num, "q_idx=%d", c->q_idx);
     BDE_REQUIRE(c->buffer_index[c->q_idx] == 0, "buffer_index[q_idx] must be 0 (the query frame is the current frame)");
     BDE_REQUIRE(c->activation == 0 || c->activation == 1, "activation=%d", c->activation);
-    BDE_REQUIRE(c->depths[c->num_encoders - 1] > 0, "depths[-1]==0 (ResidualBlockNoBN bottleneck) is not built");
+    BDE_REQUIRE(c->recurrent_type == 0 || c->recurrent_type == 1, "recurrent_type=%d (0 ConvLSTM, 1 ConvGRU)", c->recurrent_type);
+    BDE_REQUIRE(c->use_rc == 0 || c->use_rc == 1, "use_rc=%d", c->use_rc);
+    BDE_REQUIRE(c->skip_concat == 0 || c->skip_concat == 1, "skip_concat=%d", c->skip_concat);
+    BDE_REQUIRE(c->norm >= 0 && c->norm <= 2, "norm=%d (0 none, 1 BN, 2 IN)", c->norm);
+    BDE_REQUIRE(c->num_res_blocks >= 0 && c->num_res_blocks <= 64, "num_res_blocks=%d", c->num_res_blocks);
     for (int l = 0; l < c->num_encoders; ++l) {
         BDE_REQUIRE(c->depths[l] >= 0, "depths[%d]=%d", l, c->depths[l]);
         if (c->depths[l] > 0) {
@@ -1892,7 +2192,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 const char* bde_last_error(void) { return last_error_ref().c_str(); }
-int bde_abi_version(void) { return 1; }
+int bde_abi_version(void) { return 2; }
 
 int bde_create(const bde_config* cfg, bde_model** out) {
     BDE_REQUIRE(out != nullptr, "null out");
@@ -1953,17 +2253,36 @@ int bde_alloc_packed(bde_model* m) {
         m->raw[GP + k] = {sh, std::vector<float>((size_t)n, 0.f)};
     };
     const int L = c.num_encoders, ks = c.ks, bc = c.basechannels;
-    put("head.conv2d.weight", {bc, c.num_bins, ks, ks});
-    put("head.conv2d.bias", {bc});
+    auto put_convlayer = [&](const std::string& p, int cout, int cin) {      // ConvLayer / UpsampleConvLayer parameters
+        put(p + "conv2d.weight", {cout, cin, ks, ks});
+        if (c.norm != 1) put(p + "conv2d.bias", {cout});
+        if (c.norm == 1) { put(p + "norm_layer.weight", {cout}); put(p + "norm_layer.bias", {cout}); }
+        if (c.norm) { put(p + "norm_layer.running_mean", {cout}); put(p + "norm_layer.running_var", {cout}); }
+    };
+    put_convlayer("head.", bc, c.num_bins);
     const char* dirs[2] = {"forward_encoder", "backward_encoder"};
     for (int d = 0; d < 2; ++d)
         for (int l = 0; l < L; ++l) {
             std::string p = std::string(dirs[d]) + "." + std::to_string(l) + ".";
             const int ci = bc << l, co = bc << (l + 1);
-            put(p + "conv.conv2d.weight", {co, ci, ks, ks});
-            put(p + "conv.conv2d.bias", {co});
-            put(p + "recurrent_block.Gates.weight", {4 * co, 2 * co, 3, 3});
-            put(p + "recurrent_block.Gates.bias", {4 * co});
+            if (!c.use_rc) { put_convlayer(p, co, ci); continue; }
+            put_convlayer(p + "conv.", co, ci);
+            if (c.recurrent_type == 1) {
+                for (const char* gate : {"update_gate", "reset_gate", "out_gate"}) {
+                    put(p + "recurrent_block." + gate + ".weight", {co, 2 * co, 3, 3});
+                    put(p + "recurrent_block." + gate + ".bias", {co});
+                }
+            } else {
+                put(p + "recurrent_block.Gates.weight", {4 * co, 2 * co, 3, 3});
+                put(p + "recurrent_block.Gates.bias", {4 * co});
+            }
+        }
+    if (c.depths[L - 1] == 0)
+        for (int k = 0; k < c.num_res_blocks; ++k) {
+            std::string p = "feat_attns." + std::to_string(L - 1) + "." + std::to_string(1 + k) + ".";
+            const int C = bc << L;
+            put(p + "conv1.weight", {C, C, 3, 3}); put(p + "conv1.bias", {C});
+            put(p + "conv2.weight", {C, C, 3, 3}); put(p + "conv2.bias", {C});
         }
     const int tbl = (2 * c.frame_num - 1) * 169;
     for (int l = 0; l < L; ++l) {
@@ -1982,10 +2301,13 @@ int bde_alloc_packed(bde_model* m) {
         }
     }
     for (int j = 0; j < L; ++j) {
-        std::string p = "decoders." + std::to_string(j) + ".1.conv2d.";
-        put(p + "weight", {bc << (L - 1 - j), bc << (L - j), ks, ks});
-        put(p + "bias", {bc << (L - 1 - j)});
+        put_convlayer("decoders." + std::to_string(j) + ".1.", bc << (L - 1 - j), bc << (L - j));
+        if (c.skip_concat) {
+            put("decoders." + std::to_string(j) + ".0.weight", {bc << (L - j), 2 * (bc << (L - j)), 1, 1});
+            put("decoders." + std::to_string(j) + ".0.bias", {bc << (L - j)});
+        }
     }
+    if (c.skip_concat) { put("predI.0.weight", {bc, 2 * bc, 1, 1}); put("predI.0.bias", {bc}); }
     put("predI.1.weight", {1, bc, 1, 1});
     put("predI.1.bias", {1});
     return bde_finalize_weights(m);

@@ -83,7 +83,7 @@ class BDE2VID:
         missing = [k for k, _ in spec if k not in state_dict]
         used = {k for k, _ in spec}
         unexpected = [k for k in state_dict
-                      if k not in used and not k.endswith('relative_position_index')]
+                      if k not in used and not k.endswith(('relative_position_index', 'num_batches_tracked'))]
         if strict and (missing or unexpected):
             raise RuntimeError(f'load_state_dict: missing keys {missing[:5]}..., unexpected {unexpected[:5]}...')
         if missing:

@@ -32,15 +32,34 @@ def state_dict_spec(cfg: GeneratorConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     def add(k, *shape):
         spec.append((PREFIX + k, tuple(shape)))
 
-    add('head.conv2d.weight', bc, cfg.num_bins, ks, ks)
-    add('head.conv2d.bias', bc)
+    def add_conv_layer(prefix, cout, cin):
+        """ConvLayer / UpsampleConvLayer parameters (submodules.py:91-103, 123-135): no conv bias under BN; BN has an affine,
+        InstanceNorm2d(track_running_stats=True) only the running statistics."""
+        add(prefix + 'conv2d.weight', cout, cin, ks, ks)
+        if cfg.norm_kind != 1:
+            add(prefix + 'conv2d.bias', cout)
+        if cfg.norm_kind == 1:
+            add(prefix + 'norm_layer.weight', cout)
+            add(prefix + 'norm_layer.bias', cout)
+        if cfg.norm_kind:
+            add(prefix + 'norm_layer.running_mean', cout)
+            add(prefix + 'norm_layer.running_var', cout)
+
+    add_conv_layer('head.', bc, cfg.num_bins)
     for d in ('forward_encoder', 'backward_encoder'):
         for l in range(ne):
             ci, co = cfg.enc_in(l), cfg.enc_out(l)
-            add(f'{d}.{l}.conv.conv2d.weight', co, ci, ks, ks)
-            add(f'{d}.{l}.conv.conv2d.bias', co)
-            add(f'{d}.{l}.recurrent_block.Gates.weight', 4 * co, 2 * co, 3, 3)
-            add(f'{d}.{l}.recurrent_block.Gates.bias', 4 * co)
+            if not cfg.useRC:                      # a bare ConvLayer (V5.py:256-258)
+                add_conv_layer(f'{d}.{l}.', co, ci)
+                continue
+            add_conv_layer(f'{d}.{l}.conv.', co, ci)
+            if cfg.recurrent_block_type == 'convgru':          # submodules.py:348-350
+                for gate in ('reset_gate', 'update_gate', 'out_gate'):
+                    add(f'{d}.{l}.recurrent_block.{gate}.weight', co, 2 * co, 3, 3)
+                    add(f'{d}.{l}.recurrent_block.{gate}.bias', co)
+            else:
+                add(f'{d}.{l}.recurrent_block.Gates.weight', 4 * co, 2 * co, 3, 3)
+                add(f'{d}.{l}.recurrent_block.Gates.bias', 4 * co)
     for l in range(ne):  # dead on the forward path, present in checkpoints (V5.py:54-57)
         co = cfg.enc_out(l)
         add(f'fusion_layers.{l}.weight', co, 2 * co, 1, 1)
@@ -68,11 +87,22 @@ def state_dict_spec(cfg: GeneratorConfig) -> List[Tuple[str, Tuple[int, ...]]]:
             add(p + 'mlp.fc1.bias', hid)
             add(p + 'mlp.fc2.weight', C, hid)
             add(p + 'mlp.fc2.bias', C)
+    if cfg.bottleneck:                            # Sequential(ParseLayer, ResidualBlockNoBN x num_res_blocks), V5.py:77-80
+        C = cfg.enc_out(ne - 1)
+        for k in range(cfg.num_res_blocks):
+            for conv in ('conv1', 'conv2'):
+                add(f'feat_attns.{ne - 1}.{1 + k}.{conv}.weight', C, C, 3, 3)
+                add(f'feat_attns.{ne - 1}.{1 + k}.{conv}.bias', C)
     for j in range(ne):
         cin = cfg.enc_out(ne - 1 - j)
         cout = cfg.enc_in(ne - 1 - j)
-        add(f'decoders.{j}.1.conv2d.weight', cout, cin, ks, ks)
-        add(f'decoders.{j}.1.conv2d.bias', cout)
+        if cfg.skip_type == 'concat':              # 1x1 fusion of cat(skip, x), V5.py:86-89
+            add(f'decoders.{j}.0.weight', cin, 2 * cin, 1, 1)
+            add(f'decoders.{j}.0.bias', cin)
+        add_conv_layer(f'decoders.{j}.1.', cout, cin)
+    if cfg.skip_type == 'concat':                  # V5.py:92-93
+        add('predI.0.weight', bc, 2 * bc, 1, 1)
+        add('predI.0.bias', bc)
     add('predI.1.weight', cfg.num_output_channels, bc, 1, 1)
     add('predI.1.bias', cfg.num_output_channels)
     return spec
@@ -89,6 +119,10 @@ def formula_tensor(key: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
     leaf = key.rsplit('.', 1)[-1]
     if leaf == 'relative_position_bias_table':
         return (0.5 * x).astype(np.float32)
+    if leaf == 'running_var':
+        return (0.6 + 0.4 * np.abs(x)).astype(np.float32)
+    if leaf == 'running_mean':
+        return (0.2 * x).astype(np.float32)
     if re.search(r'norm\w*\.weight$', key):
         return (1.0 + 0.1 * x).astype(np.float32)
     if leaf == 'bias':
@@ -128,8 +162,10 @@ def infer_config(sd: Dict[str, torch.Tensor], **overrides) -> GeneratorConfig:
     g = {k[len(PREFIX):]: v for k, v in sd.items() if k.startswith(PREFIX)}
     hw = g['head.conv2d.weight']
     bc, num_bins, ks = int(hw.shape[0]), int(hw.shape[1]), int(hw.shape[2])
+    use_rc = 'forward_encoder.0.conv.conv2d.weight' in g
+    enc_key = 'forward_encoder.{}.conv.conv2d.weight' if use_rc else 'forward_encoder.{}.conv2d.weight'
     ne = 0
-    while f'forward_encoder.{ne}.conv.conv2d.weight' in g:
+    while enc_key.format(ne) in g:
         ne += 1
     depths, heads, tbl_rows = [], None, None
     for l in range(ne):
@@ -139,7 +175,20 @@ def infer_config(sd: Dict[str, torch.Tensor], **overrides) -> GeneratorConfig:
             tbl_rows, heads = int(t.shape[0]), int(t.shape[1])
             d += 1
         depths.append(d)
-    kw = dict(num_bins=num_bins, basechannels=bc, num_encoders=ne, ks=ks, depths=tuple(depths))
+    kw = dict(num_bins=num_bins, basechannels=bc, num_encoders=ne, ks=ks, depths=tuple(depths), useRC=use_rc)
+    if use_rc and 'forward_encoder.0.recurrent_block.reset_gate.weight' in g:
+        kw['recurrent_block_type'] = 'convgru'
+    if 'head.norm_layer.weight' in g:
+        kw['norm'] = 'BN'
+    elif 'head.norm_layer.running_mean' in g:
+        kw['norm'] = 'IN'
+    if 'decoders.0.0.weight' in g:
+        kw['skip_type'] = 'concat'
+    if ne and depths[-1] == 0:
+        k = 0
+        while f'feat_attns.{ne - 1}.{1 + k}.conv1.weight' in g:
+            k += 1
+        kw['num_res_blocks'] = k
     if heads is not None:
         kw['num_heads'] = heads
         D = (tbl_rows // (13 * 13) + 1) // 2

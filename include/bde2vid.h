@@ -40,7 +40,7 @@ extern "C" {
 typedef struct bde_model bde_model;
 
 /* Generator hyper-parameters (constructor arguments of the reference generator, V5.py:19-23).
- * Fixed by this build: norm=None, convlstm, useRC, skip 'sum', 7x7 windows, nwindow_size=None. */
+ * Fixed by this build: 7x7 windows, nwindow_size=None, one output channel, ReLU / GELU activations. */
 typedef struct bde_config {
     int32_t num_bins;                      /* input channels (5) */
     int32_t basechannels;                  /* 32 */
@@ -52,6 +52,13 @@ typedef struct bde_config {
     int32_t activation;                    /* 0 = Identity, 1 = Sigmoid */
     int32_t depths[BDE_MAX_LEVELS];        /* attention blocks per level (0 = none) */
     int32_t buffer_index[BDE_MAX_FRAMES];  /* temporal offsets of the attention buffer */
+    /* ---- constructor variants (ABI version 2; all zero / use_rc = 1 = the canonical flags) ---- */
+    int32_t recurrent_type;                /* 0 = ConvLSTM (submodules.py:278-334), 1 = ConvGRU (:337-376) */
+    int32_t use_rc;                        /* 1 = RecurrentConv encoders, 0 = bare ConvLayer encoders (V5.py:250-258) */
+    int32_t skip_concat;                   /* 0 = skip_sum, 1 = skip_concat + 1x1 fusion convs (V5.py:86-93,285-293) */
+    int32_t norm;                          /* 0 = none, 1 = BatchNorm2d, 2 = InstanceNorm2d(track_running_stats), eval mode:
+                                              folded into the convolutions at bde_finalize_weights (submodules.py:96-109) */
+    int32_t num_res_blocks;                /* ResidualBlockNoBN count of the last level when depths[last] == 0 (V5.py:77-80) */
 } bde_config;
 
 /* status codes */

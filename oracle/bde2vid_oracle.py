@@ -35,6 +35,47 @@ def conv_layer(x, w, b, stride, act: Optional[str]):
     return y
 
 
+def conv_block(x, sd, prefix, cfg, stride, act: Optional[str], upsample=False):
+    """ConvLayer.forward / UpsampleConvLayer.forward with the norm argument (submodules.py:85-114, 117-147): conv (no bias
+    under BN, :91) -> BatchNorm2d | InstanceNorm2d(track_running_stats=True), both in eval mode = the running statistics
+    (:96-103, 108-109) -> activation."""
+    if upsample:
+        x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    w = sd[prefix + 'conv2d.weight']
+    y = F.conv2d(x, w, sd.get(prefix + 'conv2d.bias'), stride=stride, padding=w.shape[-1] // 2)
+    kind = cfg.norm_kind
+    if kind == 1:
+        y = F.batch_norm(y, sd[prefix + 'norm_layer.running_mean'], sd[prefix + 'norm_layer.running_var'],
+                         sd[prefix + 'norm_layer.weight'], sd[prefix + 'norm_layer.bias'], training=False, eps=1e-5)
+    elif kind == 2:
+        y = F.instance_norm(y, sd[prefix + 'norm_layer.running_mean'], sd[prefix + 'norm_layer.running_var'], None, None,
+                            use_input_stats=False, eps=1e-5)
+    if act == 'relu':
+        y = torch.relu(y)
+    elif act == 'relu6':
+        y = torch.clamp(y, 0.0, 6.0)
+    return y
+
+
+def convgru_cell(x, h_prev, sd, pre):
+    """ConvGRU.forward (submodules.py:358-376): update / reset = sigmoid(conv3x3(cat(x, h))); candidate =
+    tanh(conv3x3(cat(x, h * reset))); h' = h (1 - update) + candidate * update.  A missing state is zeros (:364-366)."""
+    if h_prev is None:
+        h_prev = torch.zeros_like(x)
+    stacked = torch.cat([x, h_prev], dim=1)
+    update = torch.sigmoid(F.conv2d(stacked, sd[pre + 'update_gate.weight'], sd[pre + 'update_gate.bias'], padding=1))
+    reset = torch.sigmoid(F.conv2d(stacked, sd[pre + 'reset_gate.weight'], sd[pre + 'reset_gate.bias'], padding=1))
+    cand = torch.tanh(F.conv2d(torch.cat([x, h_prev * reset], dim=1), sd[pre + 'out_gate.weight'], sd[pre + 'out_gate.bias'],
+                               padding=1))
+    return h_prev * (1 - update) + cand * update
+
+
+def residual_block_no_bn(x, sd, pre):
+    """ResidualBlockNoBN.forward (V5.py:271-274): x + conv2(relu(conv1(x)))."""
+    y = torch.relu(F.conv2d(x, sd[pre + 'conv1.weight'], sd[pre + 'conv1.bias'], padding=1))
+    return x + F.conv2d(y, sd[pre + 'conv2.weight'], sd[pre + 'conv2.bias'], padding=1)
+
+
 def convlstm_cell(x, state, w, b):
     """ConvLSTM.forward (submodules.py:293-334).
 
@@ -190,12 +231,12 @@ def forward(sd: Dict[str, torch.Tensor], cfg, inputs: List[dict], capture: Optio
     rel_index = torch.from_numpy(relative_position_index(cfg.frame_num, ws, cfg.window_size[1]))
 
     # A. head conv on every frame (V5.py:116)
-    head = [conv_layer(d['events'], sd[P + 'head.conv2d.weight'], sd[P + 'head.conv2d.bias'], 1, 'relu')
-            for d in inputs]
+    head = [conv_block(d['events'], sd, P + 'head.', cfg, 1, 'relu') for d in inputs]
     if capture is not None:
         capture['head'] = torch.stack(head)
     levels = []
     target = head
+    gru = cfg.recurrent_block_type == 'convgru'
     for l in range(ne):
         # B. bidirectional recurrent sweep (V5.py:119-135): both encoders read the same sequence
         f_seq, b_seq = [None] * T, [None] * T
@@ -204,21 +245,34 @@ def forward(sd: Dict[str, torch.Tensor], cfg, inputs: List[dict], capture: Optio
             pre = f'{P}{name}.{l}.'
             state = None
             for t in order:
-                x = conv_layer(target[t], sd[pre + 'conv.conv2d.weight'], sd[pre + 'conv.conv2d.bias'],
-                               2, 'relu')                               # submodules.py:192
-                state = convlstm_cell(x, state, sd[pre + 'recurrent_block.Gates.weight'],
-                                      sd[pre + 'recurrent_block.Gates.bias'])
-                out[t] = state[0]
+                if not cfg.useRC:                                       # a bare ConvLayer (V5.py:256-258)
+                    out[t] = conv_block(target[t], sd, pre, cfg, 2, 'relu')
+                    continue
+                x = conv_block(target[t], sd, pre + 'conv.', cfg, 2, 'relu')   # submodules.py:192
+                if gru:
+                    state = convgru_cell(x, state, sd, pre + 'recurrent_block.')
+                    out[t] = state                                      # submodules.py:194
+                else:
+                    state = convlstm_cell(x, state, sd[pre + 'recurrent_block.Gates.weight'],
+                                          sd[pre + 'recurrent_block.Gates.bias'])
+                    out[t] = state[0]
         merged = [f_seq[t] + b_seq[t] for t in range(T)]                # V5.py:137-147
         if capture is not None:
             capture[f'merged{l}'] = torch.stack(merged)
         # temporal attention with in-place refinement (V5.py:151-169)
-        if cfg.depths[l] > 0:
+        if cfg.depths[l] > 0 or (l == ne - 1 and cfg.bottleneck):
             zero = torch.zeros_like(merged[0])
             for t in range(T):
                 buf = [merged[t + o] if 0 <= t + o < T else zero for o in cfg.buffer_index]
-                x = dframe_attention(buf, sd, f'{P}feat_attns.{l}.', cfg.depths[l], cfg.num_heads,
-                                     cfg.q_idx, ws, rel_index)
+                if cfg.depths[l] > 0:
+                    x = dframe_attention(buf, sd, f'{P}feat_attns.{l}.', cfg.depths[l], cfg.num_heads,
+                                         cfg.q_idx, ws, rel_index)
+                else:
+                    # Sequential(ParseLayer, ResidualBlockNoBN x n) (V5.py:77-80): ParseLayer takes buffer slot 0 (:281-282),
+                    # i.e. the frame at offset buffer_index[0] -- not the query frame
+                    x = buf[0]
+                    for k in range(cfg.num_res_blocks):
+                        x = residual_block_no_bn(x, sd, f'{P}feat_attns.{l}.{1 + k}.')
                 merged[t] = x + merged[t]
             if capture is not None:
                 capture[f'refined{l}'] = torch.stack(merged)
@@ -226,17 +280,25 @@ def forward(sd: Dict[str, torch.Tensor], cfg, inputs: List[dict], capture: Optio
         target = merged
 
     # C. decoder (V5.py:183-197); the last level is appended twice (:149-150,172) so the first
-    #    decoder sees L[-1] + L[-1]
+    #    decoder sees L[-1] + L[-1] (skip_sum) or cat(L[-1], L[-1]) (skip_concat, :285-286)
+    concat = cfg.skip_type == 'concat'
     out = []
     for t in range(T):
         x = levels[-1][t]
         for j in range(ne):
             skip = levels[ne - 1 - j][t]
-            x = upsample_conv_layer(skip + x, sd[f'{P}decoders.{j}.1.conv2d.weight'],
-                                    sd[f'{P}decoders.{j}.1.conv2d.bias'])
+            if concat:
+                x = F.conv2d(torch.cat([skip, x], dim=1), sd[f'{P}decoders.{j}.0.weight'], sd[f'{P}decoders.{j}.0.bias'])
+            else:
+                x = skip + x
+            x = conv_block(x, sd, f'{P}decoders.{j}.1.', cfg, 1, 'relu6', upsample=True)
             if capture is not None and t == 0:
                 capture[f'dec{j}_t0'] = x
-        y = F.conv2d(x + head[t], sd[P + 'predI.1.weight'], sd[P + 'predI.1.bias'])
+        if concat:
+            x = F.conv2d(torch.cat([x, head[t]], dim=1), sd[P + 'predI.0.weight'], sd[P + 'predI.0.bias'])
+        else:
+            x = x + head[t]
+        y = F.conv2d(x, sd[P + 'predI.1.weight'], sd[P + 'predI.1.bias'])
         if cfg.activation == 'Sigmoid':
             y = torch.sigmoid(y)
         out.append(y)

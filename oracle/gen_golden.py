@@ -52,6 +52,20 @@ E2E_CASES = {
     'e2e_cfgA_small': (dict(), 56, 64, 3, 1, 500),          # canonical channels/heads/depths
     'e2e_ks3': (dict(basechannels=8, ks=3, depths=(1, 0, 2), num_heads=2), 64, 56, 3, 1, 600),
 }
+# Constructor variants the reference accepts besides the assumed canonical flags (V5.py:19-23): every one a whole forward of the
+# REAL reference.  gen_variants() writes them; the name says what differs from the e2e_tiny configuration.
+_TINY = dict(basechannels=8, depths=(2, 0, 2), num_heads=4)
+VARIANT_CASES = {
+    'var_convgru': (dict(_TINY, recurrent_block_type='convgru'), 56, 64, 4, 1, 900),
+    'var_norc': (dict(_TINY, useRC=False), 56, 64, 3, 1, 910),
+    'var_concat': (dict(_TINY, skip_type='concat'), 56, 64, 3, 2, 920),
+    'var_bottleneck': (dict(_TINY, depths=(2, 0, 0), num_res_blocks=2), 56, 64, 4, 1, 930),
+    'var_bottleneck_fwd': (dict(_TINY, depths=(1, 0, 0), num_res_blocks=1, buffer_index=(1, 0, -1), q_idx=1), 56, 64, 4, 1, 935),
+    'var_bn': (dict(_TINY, norm='BN'), 56, 64, 3, 1, 940),
+    'var_in': (dict(_TINY, norm='IN'), 56, 64, 3, 1, 950),
+    'var_all': (dict(basechannels=16, depths=(1, 0, 0), num_heads=8, recurrent_block_type='convgru', skip_type='concat', norm='BN',
+                     num_res_blocks=1, ks=3), 64, 72, 3, 1, 960),
+}
 CFGA_FULL = ('e2e_cfgA_184x240', dict(), 184, 240, 4, 1, 700, 4)   # stored at pixel stride 4
 # Canonical config at every BASELINE.json resolution and at bench.py's exact workload (T=16): stored as pixels at
 # a stride plus per-frame mean/std, like CFGA_FULL.  name: (H, W, T, B, input seed, stride)
@@ -97,6 +111,19 @@ def gen_e2e():
                         meta=json.dumps(dict(cfg=cfg.to_dict(), H=H, W=W, T=T, B=B, seed=seed,
                                              weight_seed=WEIGHT_SEED, stride=stride)))
     print(name, y.shape, float(y.mean()), float(y.std()))
+
+
+def gen_variants():
+    for name, (kw, H, W, T, B, seed) in VARIANT_CASES.items():
+        cfg = _cfg(kw)
+        model = ref_import.build_reference_model(cfg, WEIGHT_SEED)
+        xs = golden_inputs(T, B, cfg.num_bins, H, W, seed)
+        with torch.no_grad():
+            ys = model([{'events': torch.from_numpy(x)} for x in xs])
+        y = torch.stack(ys).numpy()
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), out=y,
+                            meta=json.dumps(dict(cfg=cfg.to_dict(), H=H, W=W, T=T, B=B, seed=seed, weight_seed=WEIGHT_SEED)))
+        print(name, y.shape, float(y.mean()), float(y.std()), flush=True)
 
 
 def _store_sampled(name, cfg, y, stride, H, W, T, B, seed, **extra):
@@ -383,3 +410,4 @@ if __name__ == '__main__':
     gen_cfgA_sampled()
     gen_bench_fixture()
     gen_longT()
+    gen_variants()

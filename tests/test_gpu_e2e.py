@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import (load_golden, case_from_meta, maxabs, E2E_CASES, CFGA_SAMPLED, LONGT_CASES,
+from tests.util import (load_golden, case_from_meta, maxabs, E2E_CASES, CFGA_SAMPLED, LONGT_CASES, VARIANT_CASES,
                         assert_sampled)
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +27,28 @@ def test_e2e_matches_reference(name):
     m, cfg, sd, xs, y = run_case(meta)
     assert tuple(y.shape) == z['out'].shape
     assert maxabs(y, z['out']) <= TOL
+
+
+@pytest.mark.parametrize('name', sorted(VARIANT_CASES))
+def test_constructor_variants_match_reference(name):
+    """Every constructor flag of the reference generator besides the assumed canonical ones (V5.py:19-23): ConvGRU, bare
+    ConvLayer encoders (useRC=False), skip_concat with its 1x1 fusion convs, the ResidualBlockNoBN bottleneck on buffer slot 0
+    (depths[-1] == 0; buffer_index[0] negative and positive), BatchNorm / InstanceNorm in eval mode, and all of them at once --
+    against whole forwards of the real reference.  The configuration is also recovered from the state dict alone."""
+    from bde2vid_amd.model import BDE2VID
+    from bde2vid_amd.weights import infer_config
+    z, meta = load_golden(name)
+    m, cfg, sd, xs, y = run_case(meta)
+    assert tuple(y.shape) == z['out'].shape
+    assert maxabs(y, z['out']) <= TOL
+    inferred = infer_config(sd, buffer_index=cfg.buffer_index, q_idx=cfg.q_idx)
+    for k in ('recurrent_block_type', 'useRC', 'skip_type', 'norm_kind', 'depths', 'basechannels', 'ks', 'num_heads'):
+        assert getattr(inferred, k) == getattr(cfg, k), k
+    if cfg.bottleneck:
+        assert inferred.num_res_blocks == cfg.num_res_blocks
+    # the receiver side of the weight broadcast allocates the same packed layout for every variant
+    b = BDE2VID(generator=cfg).to('cuda:0').alloc_packed()
+    assert b.packed_view().shape == m.packed_view().shape
 
 
 def test_e2e_config_a_full_size():

@@ -13,7 +13,7 @@ import torch
 from oracle import bde2vid_oracle as O
 from oracle import voxel_oracle
 from tests.util import (load_golden, case_from_meta, maxabs, dense_like, voxel_like, voxel_case,
-                        E2E_CASES, GOLDEN, CFGA_SAMPLED, LONGT_CASES, bench_fixture_inputs, assert_sampled)
+                        E2E_CASES, GOLDEN, CFGA_SAMPLED, LONGT_CASES, VARIANT_CASES, bench_fixture_inputs, assert_sampled)
 from bde2vid_amd.config import GeneratorConfig
 from bde2vid_amd.weights import formula_state_dict, relative_position_index
 
@@ -23,6 +23,19 @@ P = O.P
 
 @pytest.mark.parametrize('name', sorted(E2E_CASES))
 def test_e2e_matches_reference(name):
+    z, meta = load_golden(name)
+    cfg, sd, xs = case_from_meta(meta)
+    with torch.no_grad():
+        ys = O.forward(sd, cfg, [{'events': torch.from_numpy(x)} for x in xs])
+    y = torch.stack(ys).numpy()
+    assert y.shape == z['out'].shape
+    assert maxabs(y, z['out']) <= TOL
+
+
+@pytest.mark.parametrize('name', sorted(VARIANT_CASES))
+def test_constructor_variants_match_reference(name):
+    """ConvGRU, plain (non-recurrent) encoders, skip concat, the residual-block bottleneck on buffer slot 0, BN / IN in eval
+    mode, and all of them together: whole forwards of the real reference (oracle/gen_golden.py::gen_variants)."""
     z, meta = load_golden(name)
     cfg, sd, xs = case_from_meta(meta)
     with torch.no_grad():

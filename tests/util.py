@@ -8,7 +8,7 @@ import torch
 from bde2vid_amd.config import GeneratorConfig
 from bde2vid_amd.weights import formula_state_dict
 from oracle.gen_golden import (golden_inputs, voxel_like, dense_like, voxel_case, E2E_CASES, CFGA_FULL,  # noqa: F401
-                               CFGA_SAMPLED, LONGT_CASES, BENCH_FIXTURE)
+                               CFGA_SAMPLED, LONGT_CASES, BENCH_FIXTURE, VARIANT_CASES)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
