@@ -77,10 +77,28 @@ def test_state_dict_spec_and_param_count():
 
 
 def test_unsupported_configs_raise():
-    for kw in (dict(norm='BN'), dict(recurrent_block_type='convgru'), dict(skip_type='concat'),
-               dict(depths=(4, 0, 0)), dict(nwindow_size=(3, 3)), dict(window_size=(8, 8))):
+    """What is still rejected: the flags the reference itself cannot run ('no_skip' hands a list to the decoder and raises
+    there; any recurrent block but convlstm / convgru fails its assert) and the two the kernels are not built for."""
+    for kw in (dict(nwindow_size=(3, 3)), dict(window_size=(8, 8)), dict(skip_type='no_skip'), dict(recurrent_block_type='lstm'),
+               dict(norm='GN'), dict(num_output_channels=3), dict(act_net='ELU')):
         with pytest.raises(ValueError):
             GeneratorConfig(**kw).validate()
+
+
+def test_constructor_variants_are_accepted_and_recovered_from_the_state_dict():
+    """ConvGRU / bare encoders / skip_concat / the residual bottleneck / BN / IN: accepted, their state-dict layout is the
+    reference's (key by key in tests/golden/var_*.npz through load_state_dict on the GPU box), and infer_config reads every
+    flag back from the keys alone."""
+    base = dict(basechannels=8, depths=(2, 0, 2), num_heads=4)
+    for kw in (dict(recurrent_block_type='convgru'), dict(useRC=False), dict(skip_type='concat'), dict(norm='BN'), dict(norm='IN'),
+               dict(depths=(2, 0, 0), num_res_blocks=3)):
+        cfg = GeneratorConfig(**{**base, **kw})
+        cfg.validate()
+        got = infer_config(formula_state_dict(cfg))
+        assert (got.recurrent_block_type, got.useRC, got.skip_type, got.norm_kind, got.depths) == \
+            (cfg.recurrent_block_type, cfg.useRC, cfg.skip_type, cfg.norm_kind, cfg.depths), kw
+        if cfg.bottleneck:
+            assert got.num_res_blocks == 3
 
 
 def test_relative_position_index_shape_and_range():
