@@ -40,6 +40,11 @@ SIGNATURES = {
     'bde_alloc_packed': (_I, [_P]),
     'bde_forward': (_I, [_P, _PP, _I, _I, _I, _I, _PP, _P]),
     'bde_get_intermediate': (_I, [_P, C.c_char_p, _P, _L, _P]),
+    'bde_split_begin': (_I, [_P, _PP, _I, _I, _I, _I, _P]),
+    'bde_split_sweep': (_I, [_P, _I, _I, _P]),
+    'bde_split_attend': (_I, [_P, _I, _P]),
+    'bde_split_decode': (_I, [_P, _PP, _P]),
+    'bde_split_buffer': (_I, [_P, C.c_char_p, _I, _I, C.POINTER(C.c_void_p), C.POINTER(_L)]),
     'bde_set_tuning': (_I, [_P, C.c_char_p, _L]),
     'bde_wait_outputs': (_I, [_P, _P]),
     'bde_get_info': (_I, [_P, C.c_char_p, C.POINTER(_L)]),

@@ -263,11 +263,11 @@ struct GruArgs {
     const float *gx, *gh_ur, *gh_o, *hprev;
     float *ubuf, *hr, *hout;
     long gx_gs, gx_ns, hp_gs, hp_ns, ho_gs, ho_ns;
-    int C, B;
+    int C, B, G;
     long HW;
 };
 __global__ __launch_bounds__(256) void gru_gate_kernel(const GruArgs a) {
-    const long per = (long)a.C * a.HW, total = 2L * a.B * per;
+    const long per = (long)a.C * a.HW, total = (long)a.G * a.B * per;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long z = i / per, e = i - z * per;
         const int g = (int)(z / a.B), n = (int)(z - (long)g * a.B);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const GruArgs a) {
     }
 }
 __global__ __launch_bounds__(256) void gru_out_kernel(const GruArgs a) {
-    const long per = (long)a.C * a.HW, total = 2L * a.B * per;
+    const long per = (long)a.C * a.HW, total = (long)a.G * a.B * per;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long z = i / per, e = i - z * per;
         const int g = (int)(z / a.B), n = (int)(z - (long)g * a.B);
@@ -323,7 +323,20 @@ struct PackedLayer {
     long sb_off = -1, sb_sz = 0;                // split-bf16 packing (conv_sb.h), floats; one group = sb_sz
     int sb_chunks = 0;                          // 16-channel chunks
     mutable int sb_used = 0;                    // the latest launch of this layer ran on conv_sb_kernel (bde_get_info "sb_*")
+    int G_decide = 0;                           // a one-group view of a grouped layer: choose launch shapes as for this many groups
 };
+
+// Group `g` of a grouped packed layer as a layer of its own (one sweep direction: bde_split_sweep, bde_op_encoder_conv)
+static PackedLayer group_view(const PackedLayer& pl, int g) {
+    PackedLayer v = pl;
+    v.G_decide = pl.G;
+    v.G = 1;
+    v.w_off += g * pl.w_sz;
+    if (v.b_off >= 0) v.b_off += (long)g * pl.Cout;
+    if (v.s_off >= 0) v.s_off += (long)g * pl.Cout;
+    if (v.sb_off >= 0) v.sb_off += g * pl.sb_sz;
+    return v;
+}
 
 struct Arena {
     std::vector<float> host;
@@ -641,6 +654,7 @@ struct bde_model {
     unsigned long long* tok_stamps = nullptr;
     Tuning tune;                  // launch-shape overrides (common.h), per model
     int lstm_hc8 = -1;            // recurrent step with 8-channel workgroups: -1 auto (lstm16_wants_hc8), 0 never, 1 always
+    int dir_mask = 3;             // sweep directions a recurrent level runs: bit 0 forward, bit 1 backward (bde_split_sweep sets one)
     int winblock = 1;             // one launch per attention block (winblock.h) where the level qualifies
     int winblock_sb = 1;          // ... with its GEMM phases on the bf16 matrix cores, three-term split operands (winblock_sb.h)
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
@@ -1083,7 +1097,8 @@ struct ConvCall {
 static bool conv_takes_sb(const bde_model* m, const PackedLayer& pl, int stride, int N, int Hs, int Ws) {
     const int pad = pl.KS / 2;
     const int Ho = (Hs + 2 * pad - pl.KS) / stride + 1, Wo = (Ws + 2 * pad - pl.KS) / stride + 1;
-    return m->conv_sb && pl.sb_off >= 0 && conv_sb_fits(pl.KS, stride, pl.Cout, Ws, Ho, Wo) && (long)pl.G * N * Ho * Wo >= 16384;
+    return m->conv_sb && pl.sb_off >= 0 && conv_sb_fits(pl.KS, stride, pl.Cout, Ws, Ho, Wo) &&
+           (long)(pl.G_decide ? pl.G_decide : pl.G) * N * Ho * Wo >= 16384;
 }
 
 static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
@@ -1121,6 +1136,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.w_gs = pl.w_sz;
     a.bias_gs = pl.Cout;
     a.xcd_remap = m->xcd_remap;
+    a.decide_groups = pl.G_decide;
     if (cc.out_sb) {
         a.sb_out = reinterpret_cast<unsigned short*>(cc.out_sb);
         a.sb_out_ns = (long)cdiv(pl.Cout, 16) * a.Ho * a.Wo * 48;
@@ -1311,8 +1327,13 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     Workspace& ws = m->W();
     const int Cin = m->cin(l), C = m->cout(l), h = H / 2, w = W / 2;
     const long TB = (long)T * B, hw = (long)h * w;
+    // one direction only (bde_split_sweep): one-group views of the layers, pointers moved to that direction's half
+    const int dmask = m->dir_mask, dsel = dmask == 2 ? 1 : 0;
+    const bool one_dir = dmask != 3;
+    const PackedLayer enc_v = one_dir ? group_view(m->enc[l], dsel) : m->enc[l];
+    const PackedLayer gx_v = (one_dir && m->cfg.use_rc) ? group_view(m->gx[l], dsel) : m->gx[l];
     ConvCall e;
-    e.pl = &m->enc[l];
+    e.pl = &enc_v;
     e.in = in + (long)f0 * Cin * H * W;
     e.out = ws.xenc[l] + (long)f0 * C * hw;
     e.N = nf;
@@ -1324,32 +1345,33 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     e.out_gs = TB * C * hw;
     if (!m->cfg.use_rc) {
         // bare ConvLayer encoders (V5.py:256-258): the convolution's output IS the level's feature sequence
-        e.out = ws.hseq[l] + (long)f0 * C * hw;
+        e.out = ws.hseq[l] + (long)f0 * C * hw + (one_dir ? dsel * e.out_gs : 0);
         ProfScope ps(m, pname("enc_conv", l), s);
         return run_conv(m, e, s);
     }
+    if (one_dir) e.out += dsel * e.out_gs;
     // the gate convolution reads its input as SB16 (conv_sb.h): the encoder conv's epilogue then writes that image directly
     // (6 B per element) and the fp32 planes + their conversion pass are skipped
     const long sb_fs = (long)cdiv(C, 16) * hw * SB_PIX_BYTES / 4;         // floats of one SB16 frame
-    const bool fuse = m->fuse_enc_sb && C % 32 == 0 && conv_takes_sb(m, m->gx[l], 1, nf, h, w) &&
+    const bool fuse = m->fuse_enc_sb && C % 32 == 0 && conv_takes_sb(m, gx_v, 1, nf, h, w) &&
                       ws.sb2 && split_bf16_bytes(2 * TB, C, hw) <= ws.sb2_bytes;
     if (fuse) {
-        e.out_sb = ws.sb2 + (long)f0 * sb_fs;
+        e.out_sb = ws.sb2 + (long)f0 * sb_fs + (one_dir ? dsel * TB * sb_fs : 0);
         e.out_sb_gs = TB * sb_fs;
     }
     { ProfScope ps(m, pname("enc_conv", l), s); BDE_TRY(run_conv(m, e, s)); }
     // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
     ConvCall gxc;
-    gxc.pl = &m->gx[l];
-    gxc.in = ws.xenc[l] + (long)f0 * C * hw;
-    gxc.out = ws.gx[l] + (long)f0 * m->gx[l].Cout * hw;             // rows: 4C (ConvLSTM gates) or 3C (ConvGRU)
+    gxc.pl = &gx_v;
+    gxc.in = ws.xenc[l] + (long)f0 * C * hw + (one_dir ? dsel * TB * C * hw : 0);
+    gxc.out = ws.gx[l] + (long)f0 * m->gx[l].Cout * hw + (one_dir ? dsel * TB * 4 * C * hw : 0);   // rows: 4C (ConvLSTM gates) or 3C (ConvGRU)
     gxc.N = nf;
     gxc.Hs = h;
     gxc.Ws = w;
     gxc.in_gs = TB * C * hw;
     gxc.out_gs = TB * 4 * C * hw;
     if (fuse) {
-        gxc.in = ws.sb2 + (long)f0 * sb_fs;
+        gxc.in = ws.sb2 + (long)f0 * sb_fs + (one_dir ? dsel * TB * sb_fs : 0);
         gxc.in_gs = TB * sb_fs;
         gxc.in_sb = true;
     }
@@ -1434,7 +1456,12 @@ static int run_gru_steps(bde_model* m, int l, int T, int B, int h, int w, hipStr
     const long TB = (long)T * B, hw = (long)h * w;
     float* hs = ws.hseq[l];
     const long dstride = TB * C * hw, fs = (long)B * C * hw;
-    const long total = 2L * B * C * hw;
+    const int dsel = m->dir_mask == 2 ? 1 : 0;
+    const bool one_dir = m->dir_mask != 3;
+    const int G = one_dir ? 1 : 2;
+    const PackedLayer ur_v = one_dir ? group_view(m->gru_ur[l], dsel) : m->gru_ur[l];
+    const PackedLayer o_v = one_dir ? group_view(m->gru_o[l], dsel) : m->gru_o[l];
+    const long total = (long)G * B * C * hw;
     const unsigned blocks = (unsigned)std::min<long>(cdivl(total, 256), 4096);
     for (int st = 0; st < T; ++st) {
         const int tf = st, tb = T - 1 - st;
@@ -1451,14 +1478,18 @@ static int run_gru_steps(bde_model* m, int l, int T, int B, int h, int w, hipStr
         g.hout = hs + (long)tf * fs;
         g.ho_gs = (hs + dstride + (long)tb * fs) - g.hout;
         g.ho_ns = (long)C * hw;
-        g.C = C; g.B = B; g.HW = hw;
+        g.C = C; g.B = B; g.HW = hw; g.G = G;
+        if (one_dir) {                                                 // group 0 of the launches = the chosen direction
+            g.gx += dsel * g.gx_gs;
+            g.hout += dsel * g.ho_gs;
+        }
         if (st > 0) {
-            g.hprev = hprev_f;
+            g.hprev = one_dir && dsel ? hprev_b : hprev_f;
             g.hp_gs = hprev_b - hprev_f;
             g.hp_ns = (long)C * hw;
             ConvCall ur;
-            ur.pl = &m->gru_ur[l];
-            ur.in = hprev_f; ur.in_gs = hprev_b - hprev_f;
+            ur.pl = &ur_v;
+            ur.in = g.hprev; ur.in_gs = hprev_b - hprev_f;
             ur.out = ws.gur[l]; ur.out_gs = (long)B * 2 * C * hw;
             ur.N = B; ur.Hs = h; ur.Ws = w;
             BDE_TRY(run_conv(m, ur, s));
@@ -1467,7 +1498,7 @@ static int run_gru_steps(bde_model* m, int l, int T, int B, int h, int w, hipStr
         hipLaunchKernelGGL(gru_gate_kernel, dim3(blocks), dim3(256), 0, s, g);
         if (st > 0) {
             ConvCall oc;
-            oc.pl = &m->gru_o[l];
+            oc.pl = &o_v;
             oc.in = ws.ghr[l]; oc.in_gs = (long)B * C * hw;
             oc.out = ws.gou[l]; oc.out_gs = (long)B * C * hw;
             oc.N = B; oc.Hs = h; oc.Ws = w;
@@ -1488,8 +1519,13 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     if (!enc_done && !(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
     if (!m->cfg.use_rc) return BDE_OK;
     if (m->cfg.recurrent_type == 1) return run_gru_steps(m, l, T, B, h, w, s);
-    if (!(m->debug_skip & 4) && ws.hsb[l] != nullptr) return run_recurrent_steps_sb(m, l, T, B, h, w, s);
+    if (!(m->debug_skip & 4) && ws.hsb[l] != nullptr) {
+        BDE_REQUIRE(m->dir_mask == 3, "the split-bf16 recurrent step (lstm_sb) runs both directions only");
+        return run_recurrent_steps_sb(m, l, T, B, h, w, s);
+    }
     // T recurrent steps; group 0 = forward at t = s, group 1 = backward at t = T-1-s
+    const int dsel = m->dir_mask == 2 ? 1 : 0;
+    const bool one_dir = m->dir_mask != 3;
     const PackedLayer& pl = m->lstm[l];
     float* hs = ws.hseq[l];
     const long dstride = TB * C * hw;          // direction stride inside hseq
@@ -1517,6 +1553,15 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
         a.cstate = ws.cst[l];
         a.c_gs = (long)B * C * hw;
         a.c_ns = (long)C * hw;
+        if (one_dir) {                                                 // group 0 of a one-group launch = the chosen direction
+            a.lstm_groups = 1;
+            a.in += dsel * a.in_gs;
+            a.wpk += dsel * a.w_gs;
+            a.bias += (long)dsel * 4 * C;
+            a.out += dsel * a.out_gs;
+            a.gx += dsel * a.gx_gs;
+            a.cstate += dsel * a.c_gs;
+        }
         a.N = B;
         a.Cin = C;
         a.Hin = a.Hs = h;
@@ -1529,8 +1574,8 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
             ProfScope ps(m, pname("lstm", l), s);
             const bool hc8 = m->lstm_hc8 == 1 || (m->lstm_hc8 < 0 && lstm16_wants_hc8(a));
             if (hc8) {                                   // 8-channel workgroups: their own weight packing
-                a.wpk = m->P(m->lstm8[l].w_off);
                 a.w_gs = m->lstm8[l].w_sz;
+                a.wpk = m->P(m->lstm8[l].w_off) + (one_dir ? dsel * a.w_gs : 0);
             }
             BDE_TRY(lstm16_launch(a, s, hc8));
         }
@@ -2042,6 +2087,48 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
     return BDE_OK;
 }
 
+// C. decoder for frames [f0, f0 + nf) of the [T*B] stack (V5.py:183-197)
+static int decode_frames(bde_model* mm, int f0, int nf, int T_, int B_, int H_, int W_, hipStream_t st) {
+    // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x); img = act(predI(x + head))
+    Workspace& w = mm->W();
+    const int L_ = mm->L;
+    const float* x = w.merged[L_ - 1] + (long)f0 * mm->cout(L_ - 1) * (H_ >> L_) * (W_ >> L_);
+    for (int j = 0; j < L_; ++j) {
+        const int l = L_ - 1 - j;
+        const long in_fs = (long)mm->cout(l) * (H_ >> (l + 1)) * (W_ >> (l + 1));
+        const long out_fs = (long)mm->cin(l) * (H_ >> l) * (W_ >> l);
+        ProfScope ps(mm, "decoder", st);
+        const bool fuse = (j == L_ - 1) && pred_fusable(mm);       // V5.py:195-197 in the last conv's epilogue
+        const float* skip = w.merged[l] + (long)f0 * in_fs;
+        if (mm->cfg.skip_concat) {                                 // decoder = Sequential(1x1 fusion, UpsampleConvLayer)
+            BDE_TRY(run_concat_fuse(mm, mm->dec_fuse[j], skip, x, nf, mm->cout(l), (long)(H_ >> (l + 1)) * (W_ >> (l + 1)), st));
+            x = w.fuse;
+            skip = nullptr;
+        }
+        BDE_TRY(run_decoder(mm, j, x, skip, w.dec[j] + (long)f0 * out_fs, nf,
+                            H_ >> (l + 1), W_ >> (l + 1), st,
+                            fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
+                            fuse ? w.out + (long)f0 * H_ * W_ : nullptr));
+        x = w.dec[j] + (long)f0 * out_fs;
+    }
+    if (pred_fusable(mm)) return BDE_OK;
+    const long total = (long)nf * H_ * W_;
+    long blocks = std::min<long>(cdivl(total, 256), 4096);
+    ProfScope ps(mm, "pred", st);
+    const float* hd = w.head + (long)f0 * mm->cfg.basechannels * H_ * W_;
+    if (mm->cfg.skip_concat) {                                     // predI = Sequential(1x1 fusion of cat(x, head), 1x1)
+        BDE_TRY(run_concat_fuse(mm, mm->pred_fuse, x, hd, nf, mm->cfg.basechannels, (long)H_ * W_, st));
+        x = w.fuse;
+        hd = nullptr;
+    }
+    hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x,
+                       hd, mm->P(mm->predw_off),
+                       mm->P(mm->predb_off), w.out + (long)f0 * H_ * W_, mm->cfg.basechannels, (long)H_ * W_, total,
+                       mm->cfg.activation);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
 static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s) {
     ProfScope whole(m, "forward", s);
     const bde_config& c = m->cfg;
@@ -2062,47 +2149,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
     //    (V5.py:154-169), everything that depends only on frames already refined runs on a side
     //    stream: the next level's encoder + gate convs, or (last level) the decoder.
     struct SideCtx { int l, T, B, H, W; hipStream_t main, side; bool last; int chunk; };
-    auto decode_frames = [](bde_model* mm, int f0, int nf, int T_, int B_, int H_, int W_, hipStream_t st) -> int {
-        // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x); img = act(predI(x + head))
-        Workspace& w = mm->W();
-        const int L_ = mm->L;
-        const float* x = w.merged[L_ - 1] + (long)f0 * mm->cout(L_ - 1) * (H_ >> L_) * (W_ >> L_);
-        for (int j = 0; j < L_; ++j) {
-            const int l = L_ - 1 - j;
-            const long in_fs = (long)mm->cout(l) * (H_ >> (l + 1)) * (W_ >> (l + 1));
-            const long out_fs = (long)mm->cin(l) * (H_ >> l) * (W_ >> l);
-            ProfScope ps(mm, "decoder", st);
-            const bool fuse = (j == L_ - 1) && pred_fusable(mm);       // V5.py:195-197 in the last conv's epilogue
-            const float* skip = w.merged[l] + (long)f0 * in_fs;
-            if (mm->cfg.skip_concat) {                                 // decoder = Sequential(1x1 fusion, UpsampleConvLayer)
-                BDE_TRY(run_concat_fuse(mm, mm->dec_fuse[j], skip, x, nf, mm->cout(l), (long)(H_ >> (l + 1)) * (W_ >> (l + 1)), st));
-                x = w.fuse;
-                skip = nullptr;
-            }
-            BDE_TRY(run_decoder(mm, j, x, skip, w.dec[j] + (long)f0 * out_fs, nf,
-                                H_ >> (l + 1), W_ >> (l + 1), st,
-                                fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
-                                fuse ? w.out + (long)f0 * H_ * W_ : nullptr));
-            x = w.dec[j] + (long)f0 * out_fs;
-        }
-        if (pred_fusable(mm)) return BDE_OK;
-        const long total = (long)nf * H_ * W_;
-        long blocks = std::min<long>(cdivl(total, 256), 4096);
-        ProfScope ps(mm, "pred", st);
-        const float* hd = w.head + (long)f0 * mm->cfg.basechannels * H_ * W_;
-        if (mm->cfg.skip_concat) {                                     // predI = Sequential(1x1 fusion of cat(x, head), 1x1)
-            BDE_TRY(run_concat_fuse(mm, mm->pred_fuse, x, hd, nf, mm->cfg.basechannels, (long)H_ * W_, st));
-            x = w.fuse;
-            hd = nullptr;
-        }
-        hipLaunchKernelGGL(pred_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x,
-                           hd, mm->P(mm->predw_off),
-                           mm->P(mm->predb_off), w.out + (long)f0 * H_ * W_, mm->cfg.basechannels, (long)H_ * W_, total,
-                           mm->cfg.activation);
-        BDE_HIP(hipGetLastError());
-        return BDE_OK;
-    };
-    static auto decode_fn = decode_frames;
+    static auto decode_fn = decode_frames;     // (plain function pointer for the captureless side-stream callback)
     const bool plain_flags = c.use_rc && c.recurrent_type == 0 && !c.skip_concat && c.depths[c.num_encoders - 1] > 0;
     const bool overlap = m->overlap != 0 && m->pipeline < 2 && plain_flags;   // the side stream and its events are per model, not per slot
     if (overlap && !m->side) {
@@ -2322,6 +2369,95 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
     for (int t = 0; t < T; ++t) BDE_REQUIRE(events[t] && images[t], "null frame pointer at t=%d", t);
     TuningScope ts(&m->tune);
     return forward_impl(m, events, T, B, Hp, Wp, images, (hipStream_t)stream);
+}
+
+// ---- one sequence over two GPUs, split by sweep direction (SURVEY.md §8e option 1; V5.py:122-147) --------------------------
+// Rank A runs the forward sweeps, the merge, the attention and the decoder; rank B the backward sweeps.  Per level the caller
+// moves two tensors between the ranks' workspaces (bde_split_buffer): B's hidden sequence to A before the merge, and A's level
+// output to B as the next level's input.  Every launch is the one the joint forward issues for that direction (shapes are
+// chosen as for both directions), so rank A's frames equal the single-GPU frames bit for bit.
+static int split_dims(bde_model* m, int* T, int* B, int* H, int* W) {
+    Workspace& ws = m->wslots[0];
+    BDE_REQUIRE(ws.T > 0, "bde_split_begin has not run");
+    *T = ws.T; *B = ws.B; *H = ws.H; *W = ws.W;
+    return BDE_OK;
+}
+
+int bde_split_begin(bde_model* m, const float* const* events, int32_t T, int32_t B, int32_t Hp, int32_t Wp, void* stream) {
+    BDE_REQUIRE(m && events, "null argument");
+    for (int t = 0; t < T; ++t) BDE_REQUIRE(events[t], "null frame pointer at t=%d", t);
+    TuningScope ts(&m->tune);
+    hipStream_t s = (hipStream_t)stream;
+    m->cur = 0;
+    BDE_TRY(check_dims(m, T, B, Hp, Wp));
+    BDE_TRY(ensure_workspace(m, T, B, Hp, Wp));
+    Workspace& ws = m->W();
+    BDE_TRY(copy_frames(events, ws.ev, T, (long)B * m->cfg.num_bins * Hp * Wp, 0, s));
+    ConvCall hc;
+    hc.pl = &m->head; hc.in = ws.ev; hc.out = ws.head; hc.N = T * B; hc.Hs = Hp; hc.Ws = Wp; hc.act = ACT_RELU;
+    return run_conv(m, hc, s);
+}
+
+int bde_split_sweep(bde_model* m, int32_t level, int32_t direction, void* stream) {
+    BDE_REQUIRE(m && level >= 0 && level < m->L && (direction == 0 || direction == 1), "bad argument");
+    TuningScope ts(&m->tune);
+    int T, B, H, W;
+    m->cur = 0;
+    BDE_TRY(split_dims(m, &T, &B, &H, &W));
+    Workspace& ws = m->W();
+    const float* target = level == 0 ? ws.head : ws.merged[level - 1];
+    m->dir_mask = 1 << direction;
+    const int st = run_recurrent_level(m, level, target, T, B, H >> level, W >> level, (hipStream_t)stream);
+    m->dir_mask = 3;
+    return st;
+}
+
+int bde_split_attend(bde_model* m, int32_t level, void* stream) {
+    BDE_REQUIRE(m && level >= 0 && level < m->L, "bad argument");
+    TuningScope ts(&m->tune);
+    hipStream_t s = (hipStream_t)stream;
+    int T, B, H, W;
+    m->cur = 0;
+    BDE_TRY(split_dims(m, &T, &B, &H, &W));
+    Workspace& ws = m->W();
+    const int h = H >> (level + 1), w = W >> (level + 1);
+    const long n = (long)T * B * m->cout(level) * h * w;
+    BDE_TRY(add2(ws.hseq[level], ws.hseq[level] + n, ws.merged[level], n, s));                  // V5.py:137-147
+    if (m->cfg.depths[level] > 0) return run_attention_level(m, level, T, B, h, w, s);
+    if (level == m->L - 1) return run_bottleneck_level(m, level, T, B, h, w, s);
+    return BDE_OK;
+}
+
+int bde_split_decode(bde_model* m, float* const* images, void* stream) {
+    BDE_REQUIRE(m && images, "null argument");
+    TuningScope ts(&m->tune);
+    hipStream_t s = (hipStream_t)stream;
+    int T, B, H, W;
+    m->cur = 0;
+    BDE_TRY(split_dims(m, &T, &B, &H, &W));
+    for (int t = 0; t < T; ++t) BDE_REQUIRE(images[t], "null frame pointer at t=%d", t);
+    BDE_TRY(decode_frames(m, 0, T * B, T, B, H, W, s));
+    return copy_frames(images, m->W().out, T, (long)B * H * W, 1, s);
+}
+
+int bde_split_buffer(bde_model* m, const char* what, int32_t level, int32_t direction, float** ptr, int64_t* numel) {
+    BDE_REQUIRE(m && what && ptr && numel && level >= 0 && level < m->L, "bad argument");
+    int T, B, H, W;
+    m->cur = 0;
+    BDE_TRY(split_dims(m, &T, &B, &H, &W));
+    Workspace& ws = m->W();
+    const long n = (long)T * B * m->cout(level) * (long)(H >> (level + 1)) * (W >> (level + 1));
+    const std::string k(what);
+    if (k == "hidden") {
+        BDE_REQUIRE(direction == 0 || direction == 1, "direction=%d", direction);
+        *ptr = ws.hseq[level] + (long)direction * n;
+    } else if (k == "level_out") {
+        *ptr = ws.merged[level];
+    } else {
+        return fail(BDE_ERR_ARG, "unknown split buffer '%s' (hidden | level_out)", what);
+    }
+    *numel = n;
+    return BDE_OK;
 }
 
 int bde_wait_outputs(bde_model* m, void* stream) {
@@ -2606,11 +2742,8 @@ int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* i
                         float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out && level >= 0 && level < m->L && (dir == 0 || dir == 1), "bad argument");
     TuningScope ts(&m->tune);
-    PackedLayer pl = m->enc[level];   // view of a single direction
-    pl.G = 1;
-    pl.w_off += dir * pl.w_sz;
-    pl.b_off += (long)dir * pl.Cout;
-    if (pl.sb_off >= 0) pl.sb_off += dir * pl.sb_sz;
+    PackedLayer pl = group_view(m->enc[level], dir);   // a single direction
+    pl.G_decide = 0;
     ConvCall c;
     c.pl = &pl; c.in = in; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.stride = 2; c.act = ACT_RELU;
     return run_conv(m, c, (hipStream_t)stream);

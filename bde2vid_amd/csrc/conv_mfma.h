@@ -77,6 +77,10 @@ struct ConvArgs {
     unsigned short* sb_out;
     long sb_out_gs, sb_out_ns;   // group / frame strides in bf16 elements
     int xcd_remap;               // conv_sb.h: workgroup order that keeps neighbouring tiles in one XCD's L2
+    // one sweep direction per GPU (bde_split_*): the launch covers `groups` of the layer's groups, but every launch-shape
+    // choice is made as if all `decide_groups` were present, so each direction computes exactly what the joint launch computes
+    int lstm_groups;             // recurrent step: groups in this launch (0 = both directions)
+    int decide_groups;           // 0 = the launch's own group count
 };
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: the exact-GELU

@@ -243,7 +243,7 @@ static int conv_vec_launch_ks(ConvArgs a, int G, hipStream_t stream, bool* launc
             // 5x5 conv with more than 32 output channels (decoder 128->64 at 92x120: 850 vs 680 us)
             const double pref = (KS == 5 && MT == 2) ? (nt == 1 ? 1.0 : 0.9) : (nt == 2 ? 1.0 : 0.92);
             double score = (double)a.Ho * a.Wo / launched_px * pref;
-            const long blocks = (long)(launched_px / BN) * cdiv(a.Cout, MT * 32) * G * a.N;
+            const long blocks = (long)(launched_px / BN) * cdiv(a.Cout, MT * 32) * (a.decide_groups ? a.decide_groups : G) * a.N;
             if (blocks < 512) score *= 0.5 + 0.5 * blocks / 512.0;
             if (score > best) { best = score; bnt = nt; brow = rt; }
         }

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(ROWS * PXW * 4 / SEG) __attribute__((amdgpu_waves_p
 template <int ROWS, int PXW, int SEG, bool HC8>
 static int lstm16_launch_t(const ConvArgs& a, hipStream_t stream) {
     const int Ch = a.Cout / 4;
-    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, HC8 ? 8 : 16), 2 * a.N);
+    dim3 grid(cdiv(a.Ho, ROWS) * cdiv(a.Wo, PXW), cdiv(Ch, HC8 ? 8 : 16), (a.lstm_groups ? a.lstm_groups : 2) * a.N);
     hipLaunchKernelGGL((lstm16_step_kernel<ROWS, PXW, SEG, HC8>), grid, dim3(ROWS * PXW * 4 / SEG), 0, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;

@@ -99,6 +99,19 @@ int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, 
  * (level output after attention), "dec<j>".  Layout [T][B][C][H][W]. */
 int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t numel, void* stream);
 
+/* ---- ONE sequence over TWO GPUs, split by sweep direction (V5.py:122-147: the forward and the backward RecurrentConv sweeps of a
+ * level are independent until their outputs are added).  Rank A: bde_split_begin, then per level bde_split_sweep(level, 0),
+ * receive "hidden"(level, 1) from rank B, bde_split_attend(level), send "level_out"(level) to B; finally bde_split_decode.
+ * Rank B: bde_split_begin, then per level bde_split_sweep(level, 1), send "hidden"(level, 1), receive "level_out"(level)
+ * (not after the last level).  bde_split_buffer gives the device address and length of those tensors inside the model's
+ * workspace ([T][B][C][h][w] fp32), for a P2P copy / RCCL send-recv by the caller (bde2vid_amd/dist.py::DirectionSplit).
+ * Launch shapes are chosen as in the joint forward, so rank A's frames are the single-GPU frames bit for bit. */
+int bde_split_begin(bde_model* m, const float* const* events, int32_t T, int32_t B, int32_t Hp, int32_t Wp, void* stream);
+int bde_split_sweep(bde_model* m, int32_t level, int32_t direction, void* stream);
+int bde_split_attend(bde_model* m, int32_t level, void* stream);
+int bde_split_decode(bde_model* m, float* const* images, void* stream);
+int bde_split_buffer(bde_model* m, const char* what, int32_t level, int32_t direction, float** ptr, int64_t* numel);
+
 /* Pipelined mode ("pipeline" = 2..4, see bde_set_tuning): consecutive bde_forward calls (independent
  * sequences) rotate over that many internal streams and workspaces; inputs are ordered after the
  * caller's `stream`, but the outputs of a call are only ordered into `stream` by bde_wait_outputs

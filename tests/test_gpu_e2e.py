@@ -452,3 +452,64 @@ def test_nan_voxel_grid_gives_the_reference_nan_frames():
         xs2 = case_from_meta(meta)[2]
         y2 = torch.stack(m([{'events': torch.from_numpy(x).cuda()} for x in xs2]))
     assert maxabs(y2, z['out']) <= TOL
+
+
+_SPLIT_WORKER = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from bde2vid_amd.dist import init_from_env, DirectionSplit
+from bde2vid_amd.model import build_model
+from tests.util import load_golden, case_from_meta, maxabs
+rank, world, local = init_from_env('gloo')
+assert world == 2
+report = {}
+for name in %r:
+    z, meta = load_golden(name)
+    cfg, sd, xs = case_from_meta(meta)
+    m = build_model(cfg, sd, 'cuda:0')
+    inputs = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    split = DirectionSplit(m, ranks=(0, 1))
+    with torch.no_grad():
+        ys = split(inputs)
+        ys2 = split(inputs)                       # a second call on the same workspaces
+        torch.cuda.synchronize()
+        if rank == 0:
+            joint = torch.stack(m(inputs))        # the ordinary single-GPU forward, same model object
+            y, y2 = torch.stack(ys), torch.stack(ys2)
+            report[name] = dict(equal=bool(torch.equal(y, joint)), repeat=bool(torch.equal(y, y2)),
+                                err=maxabs(y, z['out']))
+        else:
+            assert ys is None and ys2 is None
+    dist.barrier()
+if rank == 0:
+    open(os.path.join(%r, 'report.json'), 'w').write(json.dumps(report))
+dist.destroy_process_group()
+'''
+
+
+def test_one_sequence_split_over_two_ranks_by_direction(tmp_path):
+    """f-4, SURVEY.md §8(e) option 1: forward sweeps, merge, attention and decoder on rank 0, backward sweeps on rank 1, two
+    tensors exchanged per level (dist.DirectionSplit over bde_split_*).  Two processes on this one GPU over gloo -- what two
+    MI355X do over RCCL.  Rank 0's frames must equal the ordinary single-GPU forward BIT FOR BIT (every launch is the joint
+    forward's launch for that direction) and match the reference's golden frames: ConvLSTM with both attention kernels'
+    configurations, T = 1, batch 2, ConvGRU, and the bottleneck variant."""
+    import json, os, socket, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ['e2e_tiny', 'e2e_cfgA_small', 'e2e_T1', 'e2e_B2', 'e2e_buf5', 'var_convgru', 'var_bottleneck', 'var_norc']
+    script = tmp_path / 'split_worker.py'
+    script.write_text(_SPLIT_WORKER % (repo, names, str(tmp_path)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', port, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rep = json.loads((tmp_path / 'report.json').read_text())
+    assert sorted(rep) == sorted(names)
+    for name, v in rep.items():
+        assert v['equal'], f'{name}: split frames differ from the single-GPU forward'
+        assert v['repeat'], f'{name}: second split call differs'
+        assert v['err'] <= TOL, (name, v['err'])
