@@ -57,7 +57,7 @@ SIGNATURES = {
     'bde_voxelize': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     'bde_voxelize_batch': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
     'bde_voxelize_events': (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
-    'bde_voxelize_event_ranges': (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'bde_voxelize_event_ranges': (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P]),
     'bde_voxel_method': (_I, [_I]),
     'bde_find_ts_index': (_I, [_P, _L, _P, _I, _P, _P]),
     'bde_metric_mse': (_I, [_P, _P, _L, _I, _P, _P, _P]),

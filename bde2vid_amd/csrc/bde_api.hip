@@ -2655,21 +2655,37 @@ int bde_get_intermediate(bde_model* m, const char* name, float* dst, int64_t num
     return BDE_OK;
 }
 
-// 0 = tile-privatised binning (default), 1 = global float-atomic scatter (the first kernel; kept for A/B timing)
+// Binning kernel behind every bde_voxelize* call of the process: 0 = automatic (default: the bucketed path once a call is large
+// enough for its extra launch to pay, else the streaming tile kernel), 1 = global float-atomic scatter (the first kernel; A/B),
+// 2 = bucketed always, 3 = streaming tile kernel always (last round's default; A/B)
 static int& voxel_method_ref() { static int v = 0; return v; }
 int bde_voxel_method(int32_t method) {
-    BDE_REQUIRE(method == 0 || method == 1, "voxel method %d", method);
+    BDE_REQUIRE(method >= 0 && method <= 3, "voxel method %d", method);
     voxel_method_ref() = method;
     return BDE_OK;
+}
+// The bucketed path moves 29 B per event in two launches; the streaming kernel reads 4 B per event and tile (+ 9 B once) in one.
+static bool voxel_use_buckets(int nb, int H, int W, long max_win, int nseg) {
+    const int method = voxel_method_ref();
+    if (method == 2) return true;
+    if (method != 0 || max_win <= 0) return false;
+    int TH, TW, ntw, nth;
+    if (voxel_tile_geometry(nb, H, W, &TH, &TW, &ntw, &nth, 8, VB_TILE_LDS) != BDE_OK) return false;
+    const long tiles = (long)ntw * nth;
+    if (tiles > VB_MAX_TILES || TH * TW > 8192) return false;
+    return tiles >= 4 && max_win * nseg >= 2000000 && max_win >= 16384;
 }
 
 int bde_voxelize(const float* xs, const float* ys, const float* ts, const float* ps, int64_t N, int32_t num_bins,
                  int32_t H, int32_t W, float* grid, int32_t* oob_count, void* stream) {
     BDE_REQUIRE(grid && num_bins >= 1 && H >= 1 && W >= 1 && N >= 0, "bad argument");
     BDE_REQUIRE(N == 0 || (xs && ys && ts && ps), "null event array");
-    if (voxel_method_ref() == 0)
-        return voxel_tile_launch<false>(xs, ys, ts, ps, nullptr, nullptr, (long)N, 1, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
-    return voxel_launch(xs, ys, ts, ps, nullptr, 1, (long)N, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
+    if (voxel_method_ref() == 1)
+        return voxel_launch(xs, ys, ts, ps, nullptr, 1, (long)N, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
+    if (voxel_use_buckets(num_bins, H, W, (long)N, 1))
+        return voxel_bucket_launch<false>(xs, ys, ts, ps, nullptr, nullptr, (long)N, 1, (long)N, num_bins, H, W, grid, oob_count,
+                                          (hipStream_t)stream);
+    return voxel_tile_launch<false>(xs, ys, ts, ps, nullptr, nullptr, (long)N, 1, num_bins, H, W, grid, oob_count, (hipStream_t)stream);
 }
 
 int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const float* ps, const int64_t* offsets,
@@ -2678,11 +2694,14 @@ int bde_voxelize_batch(const float* xs, const float* ys, const float* ts, const 
     BDE_REQUIRE(grids && offsets && nseg >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
     BDE_REQUIRE(xs && ys && ts && ps, "null event array");
     static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
-    if (voxel_method_ref() == 0)
-        return voxel_tile_launch<false>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nseg, num_bins, H, W, grids,
-                                        oob_count, (hipStream_t)stream);
-    return voxel_launch(xs, ys, ts, ps, (const long*)offsets, nseg, (long)max_events_per_seg, num_bins, H, W, grids,
-                        oob_count, (hipStream_t)stream);
+    if (voxel_method_ref() == 1)
+        return voxel_launch(xs, ys, ts, ps, (const long*)offsets, nseg, (long)max_events_per_seg, num_bins, H, W, grids,
+                            oob_count, (hipStream_t)stream);
+    if (voxel_use_buckets(num_bins, H, W, (long)max_events_per_seg, nseg))
+        return voxel_bucket_launch<false>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nseg, (long)max_events_per_seg,
+                                          num_bins, H, W, grids, oob_count, (hipStream_t)stream);
+    return voxel_tile_launch<false>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nseg, num_bins, H, W, grids,
+                                    oob_count, (hipStream_t)stream);
 }
 
 int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, const int64_t* offsets,
@@ -2691,18 +2710,24 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
     BDE_REQUIRE(grids && offsets && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1, "bad argument");
     BDE_REQUIRE(max_events_per_window <= 0 || (xs && ys && ts && ps), "null event column");
     static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
-    if (voxel_method_ref() == 0)
-        return voxel_tile_launch<true>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nwin, num_bins, H, W, grids,
-                                       oob_count, (hipStream_t)stream);
-    return voxel_native_launch(xs, ys, ts, ps, (const long*)offsets, nwin, (long)max_events_per_window, num_bins, H, W, grids,
-                               oob_count, (hipStream_t)stream);
+    if (voxel_method_ref() == 1)
+        return voxel_native_launch(xs, ys, ts, ps, (const long*)offsets, nwin, (long)max_events_per_window, num_bins, H, W, grids,
+                                   oob_count, (hipStream_t)stream);
+    if (voxel_use_buckets(num_bins, H, W, (long)max_events_per_window, nwin))
+        return voxel_bucket_launch<true>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nwin, (long)max_events_per_window,
+                                         num_bins, H, W, grids, oob_count, (hipStream_t)stream);
+    return voxel_tile_launch<true>(xs, ys, ts, ps, (const long*)offsets, (const long*)offsets + 1, 0, nwin, num_bins, H, W, grids,
+                                   oob_count, (hipStream_t)stream);
 }
 
 int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, int64_t n_events,
-                              const int64_t* starts, const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H, int32_t W,
-                              float* grids, int32_t* oob_count, void* stream) {
+                              const int64_t* starts, const int64_t* ends, int32_t nwin, int64_t max_events_per_window, int32_t num_bins,
+                              int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream) {
     BDE_REQUIRE(grids && starts && ends && nwin >= 1 && num_bins >= 1 && H >= 1 && W >= 1 && n_events >= 0, "bad argument");
     BDE_REQUIRE(n_events == 0 || (xs && ys && ts && ps), "null event column");
+    if (voxel_method_ref() != 1 && max_events_per_window > 0 && voxel_use_buckets(num_bins, H, W, (long)max_events_per_window, nwin))
+        return voxel_bucket_launch<true>(xs, ys, ts, ps, (const long*)starts, (const long*)ends, 0, nwin, (long)max_events_per_window,
+                                         num_bins, H, W, grids, oob_count, (hipStream_t)stream, (long)n_events);
     return voxel_tile_launch<true>(xs, ys, ts, ps, (const long*)starts, (const long*)ends, 0, nwin, num_bins, H, W, grids, oob_count,
                                    (hipStream_t)stream, (long)n_events);
 }

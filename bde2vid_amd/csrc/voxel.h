@@ -268,6 +268,311 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bucketed binning: independent of the tile count.  The tile kernel above makes every tile's workgroup test every event of
+// its window (8 tiles per 180x240 grid, 50 per 480x640, 150 per 720x1280).  Here one pass moves each event ONCE: a workgroup
+// takes a chunk of VB_CHUNK consecutive events of one window, computes per event the reference's normalised time stamp and
+// its (tile, cell), and writes the chunk back sorted by tile as 8-byte records {cell | tile | polarity, t_norm} together with
+// the chunk's run offsets per tile; a tile's workgroup then reads only its own runs (VB_CHUNK / tiles records each,
+// contiguous) and accumulates in LDS as before.  29 B of traffic per event (13 read, 8 written, 8 read) whatever the tile
+// count.  Per-event arithmetic as in the kernels above (t_norm is computed once, in the bucketing pass).
+constexpr int VB_CHUNK = 4096;              // events per bucketing workgroup (256 threads x 16)
+constexpr int VB_MAX_TILES = 1024;
+constexpr long VB_TILE_LDS = 128 * 1024;    // LDS of one tile workgroup on the bucketed path (64 KB = two workgroups per CU measured
+                                            // slower at every resolution: the pass pays ~13 us per workgroup, not per byte)
+constexpr unsigned VB_NAN_WINDOW = 0x40000000u;     // flag on the last run offset of a window's first chunk
+struct VoxelRec { unsigned a; float tn; };  // a = cell (13 bits) | tile << 13 | polarity sign << 31
+
+template <bool NATIVE>
+__global__ __launch_bounds__(256) void voxel_bucket_kernel(const void* __restrict__ xs_, const void* __restrict__ ys_,
+                                                           const void* __restrict__ ts_, const void* __restrict__ ps_,
+                                                           const long* __restrict__ starts, const long* __restrict__ ends,
+                                                           long n_single, long n_cols, int nb, int H, int W, int TH, int TW,
+                                                           int ntw, int ntiles, int nchunks, VoxelRec* __restrict__ recs,
+                                                           float* __restrict__ pvals, int* __restrict__ table,
+                                                           int* __restrict__ oob) {
+    __shared__ int cnt[VB_MAX_TILES + 1];
+    __shared__ VoxelRec rec[VB_CHUNK];
+    __shared__ float recp[NATIVE ? 1 : VB_CHUNK];      // float columns carry an arbitrary weight per event (recordings: +-1 = the sign bit)
+    const int seg = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    long beg = starts ? starts[seg] : 0;
+    long end = ends ? ends[seg] : n_single;
+    if (n_cols >= 0) {
+        beg = min(max(beg, 0L), n_cols);
+        end = min(max(end, beg), n_cols);
+    }
+    int* tab = table + ((long)seg * nchunks + chunk) * (ntiles + 1);
+    const bool live = NATIVE ? (end - beg >= 3) : (end - beg > 0);     // h5_dataset.py:219-220 for recordings
+    // chunks start at the window's first event rounded DOWN to a multiple of four: a thread takes four groups of four
+    // consecutive events, each group one 8-byte (int16 columns) / 16-byte load per column (single 2-byte loads per event ran
+    // the pass at 2.4 TB/s); events in front of `beg` are masked
+    const long c0 = (beg & ~3L) + (long)chunk * VB_CHUNK;
+    if (!live || c0 >= end) {                                          // empty chunk: all runs empty
+        for (int i = tid; i <= ntiles; i += 256) tab[i] = 0;
+        return;
+    }
+    for (int i = tid; i <= ntiles; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const float bm1 = (float)(nb - 1);
+    double t0d = 0.0;
+    float t0f = 0.f, dt;
+    if (NATIVE) {
+        const double* ts = (const double*)ts_;
+        t0d = ts[beg];
+        dt = (float)(ts[end - 1] - t0d) - 0.0f;                        // event_utils.py:489 on the shifted float32 column
+    } else {
+        const float* ts = (const float*)ts_;
+        t0f = ts[beg];
+        dt = ts[end - 1] - t0f;
+    }
+    // (columns handed over as views with an odd storage offset take single loads)
+    const bool vec_ok = NATIVE ? (((reinterpret_cast<uintptr_t>(xs_) | reinterpret_cast<uintptr_t>(ys_)) & 7u) == 0 &&
+                                  (reinterpret_cast<uintptr_t>(ts_) & 15u) == 0 && (reinterpret_cast<uintptr_t>(ps_) & 3u) == 0)
+                               : (((reinterpret_cast<uintptr_t>(xs_) | reinterpret_cast<uintptr_t>(ys_) | reinterpret_cast<uintptr_t>(ts_) |
+                                    reinterpret_cast<uintptr_t>(ps_)) & 15u) == 0);
+    unsigned ra[16];
+    float rt[16], rp[16];
+    int rk[16];
+    int n_oob = 0;
+    long xq[4][4], yq[4][4];
+    float tq[4][4], pq[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i4 = c0 + (long)(k * 256 + tid) * 4;
+        if (vec_ok && i4 + 3 < end) {
+            if (NATIVE) {
+                const short4 xv = *reinterpret_cast<const short4*>((const short*)xs_ + i4);
+                const short4 yv = *reinterpret_cast<const short4*>((const short*)ys_ + i4);
+                const double2 ta = *reinterpret_cast<const double2*>((const double*)ts_ + i4);
+                const double2 tb = *reinterpret_cast<const double2*>((const double*)ts_ + i4 + 2);
+                const uchar4 pv = *reinterpret_cast<const uchar4*>((const unsigned char*)ps_ + i4);
+                xq[k][0] = xv.x; xq[k][1] = xv.y; xq[k][2] = xv.z; xq[k][3] = xv.w;
+                yq[k][0] = yv.x; yq[k][1] = yv.y; yq[k][2] = yv.z; yq[k][3] = yv.w;
+                const double td[4] = {ta.x, ta.y, tb.x, tb.y};
+                const unsigned char pb[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    tq[k][u] = ((float)(td[u] - t0d) - 0.0f) / dt * bm1;
+                    pq[k][u] = pb[u] ? 1.0f : -1.0f;
+                }
+            } else {
+                const float4 xv = *reinterpret_cast<const float4*>((const float*)xs_ + i4);
+                const float4 yv = *reinterpret_cast<const float4*>((const float*)ys_ + i4);
+                const float4 tv = *reinterpret_cast<const float4*>((const float*)ts_ + i4);
+                const float4 pv = *reinterpret_cast<const float4*>((const float*)ps_ + i4);
+                xq[k][0] = (long)xv.x; xq[k][1] = (long)xv.y; xq[k][2] = (long)xv.z; xq[k][3] = (long)xv.w;   // Tensor.long() truncates
+                yq[k][0] = (long)yv.x; yq[k][1] = (long)yv.y; yq[k][2] = (long)yv.z; yq[k][3] = (long)yv.w;
+                const float tf[4] = {tv.x, tv.y, tv.z, tv.w}, pf[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    tq[k][u] = (tf[u] - t0f) / dt * bm1;               // :490 (division, then multiply, fp32)
+                    pq[k][u] = pf[u];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = max(min(i4 + u, end - 1), beg);         // (masked below when outside [beg, end))
+                if (NATIVE) {
+                    xq[k][u] = ((const short*)xs_)[i]; yq[k][u] = ((const short*)ys_)[i];
+                    tq[k][u] = ((float)(((const double*)ts_)[i] - t0d) - 0.0f) / dt * bm1;
+                    pq[k][u] = ((const unsigned char*)ps_)[i] ? 1.0f : -1.0f;
+                } else {
+                    xq[k][u] = (long)((const float*)xs_)[i]; yq[k][u] = (long)((const float*)ys_)[i];
+                    tq[k][u] = (((const float*)ts_)[i] - t0f) / dt * bm1;
+                    pq[k][u] = ((const float*)ps_)[i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = k * 4 + u;
+            const long i = c0 + (long)(k * 256 + tid) * 4 + u;
+            rk[q] = -1;
+            if (i < beg || i >= end) continue;
+            long x = xq[k][u], y = yq[k][u];
+            if (x < 0) x += W;                                         // index_put_ wraps negative indices
+            if (y < 0) y += H;
+            if (x < 0 || x >= W || y < 0 || y >= H) { ++n_oob; continue; }   // the reference raises IndexError here
+            const int ty = (int)y / TH, tx = (int)x / TW;
+            const int tile = ty * ntw + tx;
+            const int cell = ((int)y - ty * TH) * TW + ((int)x - tx * TW);
+            const float p = pq[k][u];
+            ra[q] = (unsigned)cell | ((unsigned)tile << 13) | (p < 0.f ? 0x80000000u : 0u);
+            rt[q] = tq[k][u];
+            rp[q] = p;
+            rk[q] = atomicAdd(&cnt[tile], 1);
+        }
+    if (oob && n_oob) atomicAdd(oob, n_oob);
+    __syncthreads();
+    // exclusive scan of the per-tile counts (one wave; ntiles <= 1024 = 16 per lane)
+    if (tid < 64) {
+        const int per = (ntiles + 63) / 64;
+        int sum = 0;
+        for (int j = 0; j < per; ++j) { const int t = tid * per + j; if (t < ntiles) sum += cnt[t]; }
+        int incl = sum;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) { const int v = __shfl_up(incl, sh); if (tid >= sh) incl += v; }
+        int run = incl - sum;
+        for (int j = 0; j < per; ++j) {
+            const int t = tid * per + j;
+            if (t < ntiles) { const int c = cnt[t]; cnt[t] = run; run += c; }
+        }
+        if (tid == 63) cnt[ntiles] = incl;
+    }
+    __syncthreads();
+    // (a zero-duration window: dt == 0, or NaN from a NaN time stamp, makes every weight of the window NaN)
+    const unsigned wflag = (chunk == 0 && !(dt != 0.f && dt == dt)) ? VB_NAN_WINDOW : 0u;
+    for (int i = tid; i <= ntiles; i += 256) tab[i] = cnt[i] | (i == ntiles ? (int)wflag : 0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (rk[k] >= 0) {
+            const int pos = cnt[(ra[k] >> 13) & 0x3ffffu] + rk[k];
+            rec[pos] = VoxelRec{ra[k], rt[k]};
+            if (!NATIVE) recp[pos] = rp[k];
+        }
+    __syncthreads();
+    const int total = cnt[ntiles];
+    const long obase = ((long)seg * nchunks + chunk) * VB_CHUNK;
+    for (int i = tid; i < total; i += 256) {
+        recs[obase + i] = rec[i];
+        if (!NATIVE) pvals[obase + i] = recp[i];
+    }
+}
+
+// FIXED: the tile accumulates in 64-bit fixed point (32.32) with ds_add_u64 instead of ds_add_f32.  Measured on MI355X
+// (tools/ubench/lds_atomic_rate.hip): LDS float atomic adds retire 0.37 lanes per cycle and CU (200 G adds/s chip-wide), u32 / u64
+// adds >= 3 lanes per cycle (as fast as plain LDS stores) -- the float form was the whole cost of this pass (24 M events, two
+// taps each: 270 us).  A recording's weights are +-max(0, 1 - |t_norm - b|) with |v| <= 1: each is converted exactly up to
+// 2^-33, the sum of a pixel is exact in the 64-bit accumulator and rounded to fp32 ONCE -- closer to the real-number sum than
+// any order of float additions, and the same bits run to run.  A window of zero duration (dt == 0: every weight NaN in the
+// reference, event_utils.py:489-495) is flagged by the bucketing pass; its tile counts events per pixel and stores NaN for
+// all bins of a pixel that received one.  The float-column entry points keep float accumulation (arbitrary weights).
+template <bool FIXED>
+__global__ __launch_bounds__(1024) void voxel_tile_from_buckets_kernel(const VoxelRec* __restrict__ recs, const float* __restrict__ pvals,
+                                                                        const int* __restrict__ table, int nb, int H, int W, int TH,
+                                                                        int TW, int ntw, int ntiles, int nchunks,
+                                                                        float* __restrict__ grids) {
+    extern __shared__ __align__(8) unsigned char tile_raw[];          // [nb][TH][TW] of float | int64
+    float* tile = reinterpret_cast<float*>(tile_raw);
+    unsigned long long* tile64 = reinterpret_cast<unsigned long long*>(tile_raw);
+    const int tix = blockIdx.x, seg = blockIdx.y;
+    const int ty0 = (tix / ntw) * TH, tx0 = (tix % ntw) * TW;
+    const int th = min(TH, H - ty0), tw = min(TW, W - tx0);
+    const int tpx = TH * TW;
+    for (int i = threadIdx.x; i < nb * tpx * (FIXED ? 2 : 1); i += blockDim.x) tile[i] = 0.f;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool nan_window = FIXED && (table[((long)seg * nchunks) * (ntiles + 1) + ntiles] & VB_NAN_WINDOW) != 0;
+    auto add_event = [&](unsigned a, float t, float p) {
+        const int c0 = a & 0x1fffu;
+        if (FIXED) {
+            if (nan_window) { atomicAdd(tile64 + c0, 1ull); return; }
+        } else if (!(t == t)) {                                        // dt == 0 -> NaN weights in every bin (:494-495)
+            for (int b = 0; b < nb; ++b) atomicAdd(tile + c0 + b * tpx, p * t);
+            return;
+        }
+        const int b0 = (int)floorf(t);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b0 + k;
+            if (b < 0 || b >= nb) continue;
+            const float w = fmaxf(0.f, 1.0f - fabsf(t - (float)b));    // :494
+            const float v = p * w;                                      // :495
+            if (v == 0.f) continue;
+            if (FIXED) atomicAdd(tile64 + c0 + b * tpx, (unsigned long long)__float2ll_rn(v * 4294967296.0f));
+            else atomicAdd(tile + c0 + b * tpx, v);
+        }
+    };
+    // The tile's records are the concatenation of its runs in the window's chunks.  Per batch of 1024 chunks: every thread
+    // fetches one chunk's run bounds, a block scan turns the run lengths into positions, then thread t takes records t,
+    // t + 1024, ... of the concatenation (its chunk by bisection in LDS): two dependent memory round trips per batch instead of
+    // two per chunk -- at 300 tiles per grid a run is a dozen records and walking the chunks one after another was the whole
+    // cost of the pass.
+    __shared__ int spre[1025], slo[1024], swsum[16];
+    for (int cb = 0; cb < nchunks; cb += 1024) {
+        const int c = cb + threadIdx.x;
+        int lo = 0, len = 0;
+        if (c < nchunks) {
+            const int* tab = table + ((long)seg * nchunks + c) * (ntiles + 1);
+            lo = tab[tix] & 0xffff;
+            len = (tab[tix + 1] & 0xffff) - lo;
+        }
+        int incl = len;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) { const int v = __shfl_up(incl, sh); if (lane >= sh) incl += v; }
+        if (lane == 63) swsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += swsum[w];
+        spre[threadIdx.x] = base + incl - len;
+        slo[threadIdx.x] = lo;
+        if (threadIdx.x == 1023) spre[1024] = base + incl;
+        __syncthreads();
+        const int total = spre[1024];
+        const long rb0 = ((long)seg * nchunks + cb) * VB_CHUNK;
+        for (int v0 = threadIdx.x; v0 < total; v0 += 4 * 1024) {
+            VoxelRec e[4];
+            float pv[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * 1024;
+                ok[u] = v < total;
+                const int vv = ok[u] ? v : 0;
+                int k = 0;                                              // largest k with spre[k] <= vv
+#pragma unroll
+                for (int step = 512; step >= 1; step >>= 1)
+                    if (spre[k + step] <= vv) k += step;
+                const long j = rb0 + (long)k * VB_CHUNK + slo[k] + (vv - spre[k]);
+                e[u] = recs[j];
+                pv[u] = (!FIXED && pvals) ? pvals[j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) add_event(e[u].a, e[u].tn, (!FIXED && pvals) ? pv[u] : ((e[u].a & 0x80000000u) ? -1.0f : 1.0f));
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    float* grid = grids + (long)seg * nb * H * W;
+    for (int i = threadIdx.x; i < nb * th * tw; i += blockDim.x) {
+        const int b = i / (th * tw), r = i - b * th * tw;
+        const int ly = r / tw, lx = r - ly * tw;
+        float v;
+        if (FIXED) {
+            if (nan_window) v = tile64[ly * TW + lx] ? __builtin_nanf("") : 0.f;
+            else v = (float)((double)(long long)tile64[(b * TH + ly) * TW + lx] * 2.3283064365386963e-10);   // exact product, one rounding
+        } else {
+            v = tile[(b * TH + ly) * TW + lx];
+        }
+        grid[((long)b * H + ty0 + ly) * W + tx0 + lx] = v;
+    }
+}
+
+// scratch of the bucketed path (records + run tables), one buffer per device, grown on demand
+struct VoxelScratch { void* p = nullptr; size_t bytes = 0; };
+inline int voxel_scratch(size_t need, void** out) {
+    static VoxelScratch pool[BDE_MAX_DEVICES];
+    static std::mutex mu;
+    int d = 0;
+    BDE_HIP(hipGetDevice(&d));
+    if (d < 0 || d >= BDE_MAX_DEVICES) return fail(BDE_ERR_ARG, "device %d", d);
+    std::lock_guard<std::mutex> lock(mu);
+    VoxelScratch& s = pool[d];
+    if (s.bytes < need) {
+        if (s.p) { BDE_HIP(hipDeviceSynchronize()); BDE_HIP(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
+        const size_t sz = need + need / 4;
+        BDE_HIP(hipMalloc(&s.p, sz));
+        s.bytes = sz;
+    }
+    *out = s.p;
+    return BDE_OK;
+}
+
 // find_ts_index of DynamicH5Dataset (data_loader/h5_dataset.py:444-446) = binary_search_h5_dset (event_utils.py:10-28,
 // side='left') on the events/ts column: the SAME bisection per query -- on an exact hit it returns the index the
 // bisection lands on (not necessarily the first of equal timestamps), otherwise the insertion point.
@@ -310,6 +615,57 @@ static inline int voxel_tile_launch(const void* xs, const void* ys, const void* 
         hipLaunchKernelGGL(voxel_tile_kernel<NATIVE>, dim3((unsigned)(nth * ntw), (unsigned)nw), dim3(1024), lds, stream, xs, ys, ts, ps,
                            starts ? starts + w0 : nullptr, ends ? ends + w0 : nullptr, n_single, n_cols, nb, H, W, TH, TW, ntw,
                            grids + (long)w0 * nb * H * W, oob);
+    }
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+// tile geometry shared by the two tile-privatised paths
+static inline int voxel_tile_geometry(int nb, int H, int W, int* TH_, int* TW_, int* ntw_, int* nth_, int cell_bytes = 4,
+                                      long lds_budget = 128 * 1024) {
+    const long cap = std::min<long>(lds_budget / ((long)cell_bytes * nb), 8192);   // pixels of one tile: all bins within the LDS budget
+    if (cap < 64) return fail(BDE_ERR_UNSUPPORTED, "voxel grid with %d bins does not fit the LDS tile", nb);
+    int ntw = cdiv(W, 128);
+    int TW = cdiv(W, ntw);
+    while ((long)TW > cap) { ++ntw; TW = cdiv(W, ntw); }
+    int TH = (int)std::min<long>(H, cap / TW);
+    const int nth = cdiv(H, TH);
+    TH = cdiv(H, nth);
+    *TH_ = TH; *TW_ = TW; *ntw_ = ntw; *nth_ = nth;
+    return BDE_OK;
+}
+
+// Bucketed path.  max_win = an upper bound of the events of one window (sizes the chunk grid and the scratch).
+template <bool NATIVE>
+static inline int voxel_bucket_launch(const void* xs, const void* ys, const void* ts, const void* ps, const long* starts,
+                                      const long* ends, long n_single, int nseg, long max_win, int nb, int H, int W, float* grids,
+                                      int* oob, hipStream_t stream, long n_cols = -1) {
+    if (oob) BDE_HIP(hipMemsetAsync(oob, 0, sizeof(int), stream));
+    if (nseg <= 0) return BDE_OK;
+    constexpr int CELL = NATIVE ? 8 : 4;                // recordings accumulate in 64-bit fixed point
+    int TH, TW, ntw, nth;
+    BDE_TRY(voxel_tile_geometry(nb, H, W, &TH, &TW, &ntw, &nth, CELL, VB_TILE_LDS));
+    const int ntiles = nth * ntw;
+    if (ntiles > VB_MAX_TILES || TH * TW > 8192) return fail(BDE_ERR_UNSUPPORTED, "bucketed binning: %d tiles of %d pixels", ntiles, TH * TW);
+    const int nchunks = (int)std::max<long>(1, cdivl(std::max<long>(max_win, 0) + 3, VB_CHUNK));   // (+ 3: chunks start at a multiple of four)
+    const size_t lds = (size_t)CELL * nb * TH * TW;
+    static unsigned char raised[BDE_MAX_DEVICES];
+    BDE_HIP(raise_dynamic_lds(raised, (const void*)voxel_tile_from_buckets_kernel<NATIVE>, 144 * 1024));   // (+ 8.3 KB of static LDS)
+    for (int w0 = 0; w0 < nseg; w0 += 65535) {
+        const int nw = std::min(65535, nseg - w0);
+        const size_t nrec = (size_t)nw * nchunks * VB_CHUNK;
+        const size_t rec_bytes = nrec * sizeof(VoxelRec), p_bytes = NATIVE ? 0 : nrec * sizeof(float);
+        const size_t tab_bytes = (size_t)nw * nchunks * (ntiles + 1) * sizeof(int);
+        void* scratch = nullptr;
+        BDE_TRY(voxel_scratch(rec_bytes + p_bytes + tab_bytes + 512, &scratch));
+        VoxelRec* recs = (VoxelRec*)scratch;
+        float* pvals = NATIVE ? nullptr : (float*)((char*)scratch + rec_bytes);
+        int* table = (int*)((char*)scratch + ((rec_bytes + p_bytes + 255) / 256) * 256);
+        hipLaunchKernelGGL(voxel_bucket_kernel<NATIVE>, dim3((unsigned)nchunks, (unsigned)nw), dim3(256), 0, stream, xs, ys, ts, ps,
+                           starts ? starts + w0 : nullptr, ends ? ends + w0 : nullptr, n_single, n_cols, nb, H, W, TH, TW, ntw, ntiles,
+                           nchunks, recs, pvals, table, oob);
+        hipLaunchKernelGGL(voxel_tile_from_buckets_kernel<NATIVE>, dim3((unsigned)ntiles, (unsigned)nw), dim3(1024), lds, stream, recs, pvals, table,
+                           nb, H, W, TH, TW, ntw, ntiles, nchunks, grids + (long)w0 * nb * H * W);
     }
     BDE_HIP(hipGetLastError());
     return BDE_OK;

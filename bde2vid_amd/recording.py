@@ -215,6 +215,7 @@ class Recording:
             _lib.check(_lib.lib().bde_voxelize_event_ranges(
                 C.c_void_p(self.xs.data_ptr()), C.c_void_p(self.ys.data_ptr()), C.c_void_p(self.ts.data_ptr()),
                 C.c_void_p(self.ps.data_ptr()), self.ts.numel(), C.c_void_p(se[0].data_ptr()), C.c_void_p(se[1].data_ptr()), n,
+                max(b - a for a, b in idx),
                 self.num_bins, H, W, C.c_void_p(grids.data_ptr()), C.c_void_p(oob.data_ptr()), st))
         if check_bounds and int(oob.item()) != 0:
             raise IndexError(f'{int(oob.item())} events fall outside the {H}x{W} sensor '

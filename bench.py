@@ -214,36 +214,42 @@ def voxel_report(device, T, sensor_hw, n_events, vox_dt):
     large launch against the float-atomic roof, and the reference's algorithm timed on one host core."""
     import numpy as np
     import torch
+    from bde2vid_amd import _lib
     from bde2vid_amd.events import events_to_voxel_windows
     from bde2vid_amd.synth import synthetic_recording
     sh, sw = sensor_hw
     out = {'events_per_s': n_events / vox_dt, 'events': n_events,
            'note': 'HIP scatter incl. H2D of the events; outside the timed region'}
 
-    def run(n, nwin, reps):
-        xs, ys, ts, ps, _ = synthetic_recording(n, sh, sw, 4, 77)
+    def run(n, nwin, reps, sensor=(sh, sw), method=0):
+        h_, w_ = sensor
+        xs, ys, ts, ps, _ = synthetic_recording(n, h_, w_, 4, 77)
         idx = np.arange(nwin + 1, dtype=np.int64) * (n // nwin)
         cols = [torch.from_numpy(a).to(device) for a in (xs, ys, ts, ps)]
         idx_d = torch.from_numpy(idx)
-        events_to_voxel_windows(*cols, idx_d, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            events_to_voxel_windows(*cols, idx_d, 5, sensor_size=(sh, sw), device=device, check_bounds=False)
-        e1.record()
-        torch.cuda.synchronize()
+        _lib.check(_lib.lib().bde_voxel_method(method))
+        try:
+            events_to_voxel_windows(*cols, idx_d, 5, sensor_size=(h_, w_), device=device, check_bounds=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                events_to_voxel_windows(*cols, idx_d, 5, sensor_size=(h_, w_), device=device, check_bounds=False)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(_lib.lib().bde_voxel_method(0))
         dt = e0.elapsed_time(e1) * 1e-3 / reps
         nn = int(idx[-1])
-        # tiles per grid as csrc/voxel.h::voxel_tile_launch picks them: every tile's workgroup streams the window's events
+        # pixel tiles per grid as csrc/voxel.h picks them
         cap = (128 * 1024) // (4 * 5)
-        ntw = -(-sw // 128)
-        tw = -(-sw // ntw)
-        th = min(sh, cap // tw)
-        tiles = -(-sh // th) * ntw
-        alg = nn * 13 + nwin * 5 * sh * sw * 4             # every event column byte read once, every grid cell written once
-        return dict(events=nn, windows=nwin, events_per_s=nn / dt, ms_per_call=dt * 1e3, algorithmic_GBps=alg / dt / 1e9,
-                    tiles_per_grid=tiles, streamed_GBps=(nn * 13 * tiles + nwin * 5 * sh * sw * 4) / dt / 1e9)
+        ntw = -(-w_ // 128)
+        tw = -(-w_ // ntw)
+        th = min(h_, cap // tw)
+        tiles = -(-h_ // th) * ntw
+        alg = nn * 13 + nwin * 5 * h_ * w_ * 4             # every event column byte read once, every grid cell written once
+        return dict(events=nn, windows=nwin, sensor=[h_, w_], events_per_s=nn / dt, ms_per_call=dt * 1e3,
+                    algorithmic_GBps=alg / dt / 1e9, tiles_per_grid=tiles)
     small = run(T * (sh * sw // 2), T, 20)
     small['note'] = ('int16/int16/float64/bool columns resident in HBM, one grid per window; HIP events on the launch stream '
                      'around the Python call (offsets H2D and allocation included): launch-bound at this size')
@@ -251,10 +257,16 @@ def voxel_report(device, T, sensor_hw, n_events, vox_dt):
     big = run(24_000_000, 64, 3)
     big['roofline'] = {'bound': 'hbm', 'achieved': big['algorithmic_GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                        'frac': big['algorithmic_GBps'] / HBM_PEAK_GBPS,
-                       'note': 'algorithmic bytes (13 B per event + 4 B per grid cell) / time; the tile-privatised kernel streams '
-                               'a window\'s events once per pixel tile (streamed_GBps, mostly L2 / Infinity Cache hits); the '
-                               'global-atomic scatter it replaced sat on the 0.08 TB/s scattered float-atomic roof '
-                               '(MI355X_MICROARCH.md): 2.36 ms for the same 24 M events'}
+                       'note': 'algorithmic bytes (13 B per event + 4 B per grid cell) / time; bucketed binning (csrc/voxel.h): one pass '
+                               'moves every event once into the run of its (window, pixel tile) as an 8-byte record, the tile '
+                               'workgroups read only their own runs: 29 B of traffic per event whatever the tile count.  '
+                               '`streaming` = last round\'s kernel (every tile\'s workgroup reads its window\'s events), same call'}
+    big['streaming'] = {k: v for k, v in run(24_000_000, 64, 3, method=3).items() if k in ('ms_per_call', 'algorithmic_GBps')}
+    vga = run(24_000_000, 64, 3, sensor=(480, 640))
+    vga['roofline'] = {'bound': 'hbm', 'achieved': vga['algorithmic_GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                       'frac': vga['algorithmic_GBps'] / HBM_PEAK_GBPS}
+    vga['streaming'] = {k: v for k, v in run(24_000_000, 64, 3, sensor=(480, 640), method=3).items() if k in ('ms_per_call', 'algorithmic_GBps')}
+    out['native_columns_24M_vga'] = vga
     out['native_columns_24M'] = big
     return out
 

@@ -188,12 +188,16 @@ int bde_voxelize_events(const int16_t* xs, const int16_t* ys, const double* ts, 
 /* The same for arbitrary, possibly overlapping windows [starts[w], ends[w]) (device int64 [nwin] each): the k_events and
  * t_seconds voxel methods with a sliding window (h5_dataset.py:277-302).  n_events = length of the four columns: window
  * bounds beyond it are clamped on the device (what an h5py slice does with a file whose attributes overstate its datasets),
- * so no window can read past the columns. */
+ * so no window can read past the columns.  max_events_per_window = an upper bound of ends[w] - starts[w] known to the host
+ * (it sizes the bucketed path; a window longer than the bound would lose its tail there), or 0 = unknown: the streaming
+ * kernel is used. */
 int bde_voxelize_event_ranges(const int16_t* xs, const int16_t* ys, const double* ts, const uint8_t* ps, int64_t n_events,
-                              const int64_t* starts, const int64_t* ends, int32_t nwin, int32_t num_bins, int32_t H,
-                              int32_t W, float* grids, int32_t* oob_count, void* stream);
-/* Binning kernel behind all bde_voxelize* calls of the process: 0 (default) = a workgroup per (window, pixel tile)
- * accumulates in LDS and stores the tile; 1 = one global float atomic per tap (kept for A/B timing). */
+                              const int64_t* starts, const int64_t* ends, int32_t nwin, int64_t max_events_per_window,
+                              int32_t num_bins, int32_t H, int32_t W, float* grids, int32_t* oob_count, void* stream);
+/* Binning kernel behind all bde_voxelize* calls of the process: 0 (default) = automatic: large calls are bucketed (one pass moves
+ * every event once into the run of its (window, pixel tile), 29 B of traffic per event whatever the tile count; csrc/voxel.h),
+ * small ones stream (a workgroup per (window, pixel tile) reads the window's events and accumulates its tile in LDS);
+ * 1 = one global float atomic per tap; 2 = bucketed always; 3 = streaming always (1 and 3: kept for A/B timing). */
 int bde_voxel_method(int32_t method);
 /* DynamicH5Dataset.find_ts_index (h5_dataset.py:444-446 -> event_utils.py:10-28) for nq timestamps at once on the
  * device-resident events/ts column (float64 [n], ascending): out[i] = the index the reference's bisection returns. */
