@@ -22,6 +22,7 @@
 #include "pw_gemm.h"
 #include "token_fused.h"
 #include "lstm16.h"
+#include "lstm_sb.h"
 #include "winblock.h"
 #include "winblock_sb.h"
 #include "wideblock.h"
@@ -489,6 +490,35 @@ static PackedLayer pack_lstm8(Arena& ar, const std::vector<const DenseLayer*>& g
     return pl;
 }
 
+// lstm_sb.h: h-part of the gates as three bf16 terms, rows GATE-INTERLEAVED (row 8 q + 4 hl + gate of tile rt = that gate of hidden
+// channel 8 rt + 4 hl + q), A-fragment order of v_mfma_f32_32x32x16_bf16: [group][row tile][chunk 16][tap][term][64 lanes][8]
+static void pack_lstm_sbk(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
+    const DenseLayer& d0 = *groups[0];
+    const int Ch = d0.rows / 4, nrt = cdiv(Ch, 8), C16 = cdiv(d0.Cin, 16);
+    const long per_group_u16 = (long)nrt * C16 * 9 * 3 * 64 * 8;
+    pl.Cin = d0.Cin; pl.Cout = d0.rows; pl.KS = 3; pl.G = (int)groups.size();
+    pl.sb_sz = per_group_u16 / 2;
+    pl.sb_chunks = C16;
+    pl.sb_off = ar.alloc(pl.sb_sz * (long)groups.size());
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const DenseLayer& d = *groups[g];
+        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + pl.sb_off + (long)g * pl.sb_sz);
+        for (int rt = 0; rt < nrt; ++rt)
+            for (int ch = 0; ch < C16; ++ch)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            // row rho = 8 q + 4 hl + gate  <->  hidden channel 8 rt + 4 hl + q (lstm_sb.h)
+                            const int rho = l & 31, hc = rt * 8 + 4 * ((rho >> 2) & 1) + (rho >> 3), gate = rho & 3, ci = ch * 16 + 8 * (l >> 5) + j;
+                            const float w = (hc < Ch && ci < d.Cin) ? d.w[((long)(gate * Ch + hc) * d.Cin + ci) * 9 + tap] : 0.f;
+                            unsigned short t3[3];
+                            sb_split3(w, t3[0], t3[1], t3[2]);
+                            for (int k = 0; k < 3; ++k)
+                                dst[(((((long)rt * C16 + ch) * 9 + tap) * 3 + k) * 64 + l) * 8 + j] = t3[k];
+                        }
+    }
+}
+
 // conv_sb.h: the weights as three bf16 terms in A-fragment order of v_mfma_f32_32x32x16_bf16:
 // [group][co tile 32][chunk 16][tap][term][64 lanes][8]: lane l = W[32 tile + (l & 31)][16 chunk + 8 (l >> 5) + j][tap]
 static void pack_split_bf16(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
@@ -590,6 +620,7 @@ struct Workspace {
     std::vector<float*> gur, ghr, gou, gub;   // ConvGRU per level: h-parts of update | reset, h * reset, h-part of the candidate, update gate
     float *cat = nullptr, *fuse = nullptr;    // skip_concat: cat(skip, x) and the 1x1 fusion's output
     float *rbA = nullptr, *rbX[2] = {nullptr, nullptr}, *zero_l = nullptr;   // bottleneck: conv1 output, block outputs, a zero frame
+    std::vector<float*> hsk;      // per level: hidden state as SB16, two buffers [2][2 dirs][B][C16][hw] (lstm_sb.h)
     std::vector<float*> hsb, ghb; // per level: hidden state as SB16, two buffers [2][2 dirs][B][C16][hw] / h-part of the gates [2][B][4C][hw]
     long sb_bytes = 0;
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
@@ -618,6 +649,7 @@ struct bde_model {
     PackedLayer head, pred_dummy;
     std::vector<PackedLayer> enc, gx, lstm, lstm8, dec;   // enc/gx/lstm: G=2 (fwd,bwd); lstm8 = the 8-channel-workgroup packing
     std::vector<PackedLayer> lstm_sb;                     // h-part of the gates, split-bf16 packing only (conv_sb.h)
+    std::vector<PackedLayer> lstm_sbk;                    // ... gate-interleaved rows for the fused step kernel (lstm_sb.h)
     std::vector<PackedLayer> gru_ur, gru_o;               // ConvGRU: h-parts of update | reset and of the candidate (G = 2)
     std::vector<PackedLayer> dec_fuse;                    // skip_concat: 1x1 fusion conv in front of decoder j
     PackedLayer pred_fuse;                                // ... and in front of predI
@@ -662,6 +694,7 @@ struct bde_model {
     int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
     int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
     int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
+    int use_lstm_sbk = 1;         // recurrent step on the bf16 matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
@@ -809,6 +842,7 @@ static int build_packed(bde_model* m) {
     m->lstm.assign(L, PackedLayer());
     m->lstm8.assign(L, PackedLayer());
     m->lstm_sb.assign(L, PackedLayer());
+    m->lstm_sbk.assign(L, PackedLayer());
     m->dec.assign(L, PackedLayer());
     m->attn.assign(L, AttnLevel());
     m->gru_ur.assign(L, PackedLayer());
@@ -878,6 +912,7 @@ static int build_packed(bde_model* m) {
             ps.Cin = co; ps.Cout = 4 * co; ps.KS = 3; ps.G = 2;
             pack_split_bf16(ar, ps, {&gh[0], &gh[1]});
         }
+        if (co % 16 == 0) pack_lstm_sbk(ar, m->lstm_sbk[l], {&gh[0], &gh[1]});
     }
     if (c.depths[L - 1] == 0) {
         // Sequential(ParseLayer, ResidualBlockNoBN x num_res_blocks) in place of the last level's attention (V5.py:77-80)
@@ -1214,6 +1249,7 @@ static int ws_alloc(Workspace& ws, float** p, long numel) {
 static bool winblock_ok(const bde_model* m, int l);
 static bool wide_ok(const bde_model* m, int l);
 static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w);
+static bool lstm_sbk_ok(const bde_model* m, int l, int h, int w);
 
 static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     Workspace& ws = m->W();
@@ -1226,7 +1262,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     BDE_TRY(ws_alloc(ws, &ws.head, TB * c.basechannels * H * W));
     BDE_TRY(ws_alloc(ws, &ws.out, TB * H * W));
     ws.xenc.assign(L, nullptr); ws.gx.assign(L, nullptr); ws.hseq.assign(L, nullptr); ws.cst.assign(L, nullptr);
-    ws.hsb.assign(L, nullptr); ws.ghb.assign(L, nullptr);
+    ws.hsb.assign(L, nullptr); ws.ghb.assign(L, nullptr); ws.hsk.assign(L, nullptr);
     ws.gur.assign(L, nullptr); ws.ghr.assign(L, nullptr); ws.gou.assign(L, nullptr); ws.gub.assign(L, nullptr);
     const bool gru = c.use_rc && c.recurrent_type == 1;
     ws.merged.assign(L, nullptr); ws.mergedT.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
@@ -1244,6 +1280,8 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
             BDE_TRY(ws_alloc(ws, &ws.gou[l], 2L * B * C * hw));
             BDE_TRY(ws_alloc(ws, &ws.gub[l], 2L * B * C * hw));
         }
+        if (!gru && c.use_rc && lstm_sbk_ok(m, l, H >> (l + 1), W >> (l + 1)))
+            BDE_TRY(ws_alloc(ws, &ws.hsk[l], 2 * split_bf16_bytes(2L * B, (int)C, hw) / 4 + 4));
         if (!gru && c.use_rc && lstm_sb_ok(m, l, B, H >> (l + 1), W >> (l + 1))) {
             BDE_TRY(ws_alloc(ws, &ws.hsb[l], 2 * split_bf16_bytes(2L * B, (int)C, hw) / 4 + 4));
             BDE_TRY(ws_alloc(ws, &ws.ghb[l], 2L * B * 4 * C * hw));
@@ -1347,7 +1385,9 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
         // bare ConvLayer encoders (V5.py:256-258): the convolution's output IS the level's feature sequence
         e.out = ws.hseq[l] + (long)f0 * C * hw + (one_dir ? dsel * e.out_gs : 0);
         ProfScope ps(m, pname("enc_conv", l), s);
-        return run_conv(m, e, s);
+        const int st = run_conv(m, e, s);
+        m->enc[l].sb_used = enc_v.sb_used;
+        return st;
     }
     if (one_dir) e.out += dsel * e.out_gs;
     // the gate convolution reads its input as SB16 (conv_sb.h): the encoder conv's epilogue then writes that image directly
@@ -1360,6 +1400,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
         e.out_sb_gs = TB * sb_fs;
     }
     { ProfScope ps(m, pname("enc_conv", l), s); BDE_TRY(run_conv(m, e, s)); }
+    m->enc[l].sb_used = enc_v.sb_used;                                   // (the launch ran on a copy / one-direction view of the layer)
     // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
     ConvCall gxc;
     gxc.pl = &gx_v;
@@ -1376,6 +1417,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
         gxc.in_sb = true;
     }
     { ProfScope ps(m, pname("gates_x", l), s); BDE_TRY(run_conv(m, gxc, s)); }
+    m->gx[l].sb_used = gx_v.sb_used;
     return BDE_OK;
 }
 
@@ -1392,6 +1434,61 @@ static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w) {
     if (m->lstm_sb_mode == 1) return true;
     const long wgs = cdivl((long)h * w, 128) * cdivl(4 * C, 128) * 2 * B;
     return wgs >= 160 && cdiv(C, 16) <= 8;
+}
+
+// The fused split-bf16 step (lstm_sb.h): one launch per time step, h carried as SB16 between steps (two buffers).
+static bool lstm_sbk_ok(const bde_model* m, int l, int h, int w) {
+    if (!m->use_lstm_sbk || m->lstm_sb_mode != 0 || !m->conv_sb) return false;
+    if ((size_t)l >= m->lstm_sbk.size() || m->lstm_sbk[l].sb_off < 0) return false;
+    return lstm_sb_shape(m->cout(l), h, w).ok;
+}
+
+static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
+    Workspace& ws = m->W();
+    const int C = m->cout(l);
+    const long TB = (long)T * B, hw = (long)h * w;
+    const PackedLayer& pl = m->lstm_sbk[l];
+    float* hs = ws.hseq[l];
+    const long dstride = TB * C * hw, fs = (long)B * C * hw;
+    const long sb_ns = (long)cdiv(C, 16) * hw * SB_PIX_BYTES;              // bytes of one frame's SB16 image
+    const long sb_buf = 2L * B * sb_ns;                                    // one buffer: both directions
+    const int dsel = m->dir_mask == 2 ? 1 : 0;
+    const bool one_dir = m->dir_mask != 3;
+    unsigned char* hsk = reinterpret_cast<unsigned char*>(ws.hsk[l]);
+    for (int st = 0; st < T; ++st) {
+        const int tf = st, tb = T - 1 - st;
+        ProfScope ps(m, pname("lstm", l), s);
+        LstmSbArgs a;
+        memset(&a, 0, sizeof a);
+        a.hin = hsk + ((st + 1) & 1) * sb_buf;
+        a.hsb = hsk + (st & 1) * sb_buf;
+        a.hin_gs = (long)B * sb_ns;
+        a.hin_ns = sb_ns;
+        a.wpk = reinterpret_cast<const unsigned short*>(m->P(pl.sb_off));
+        a.w_gs = pl.sb_sz * 2;
+        a.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
+        a.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - a.gx;
+        a.gx_ns = (long)4 * C * hw;
+        a.cstate = ws.cst[l];
+        a.c_gs = (long)B * C * hw;
+        a.c_ns = (long)C * hw;
+        a.hout = hs + (long)tf * fs;
+        a.ho_gs = (hs + dstride + (long)tb * fs) - a.hout;
+        a.ho_ns = (long)C * hw;
+        a.zeros = m->P(m->zero_off);
+        a.B = B; a.Ch = C; a.H = h; a.W = w;
+        a.first = st == 0;
+        a.stamps = (st == T / 2) ? m->tok_stamps : nullptr;                // diagnostics (bde_debug_token_stamps): one mid-sweep step
+        if (one_dir) {                                                     // group 0 of a one-group launch = the chosen direction
+            a.hin += dsel * a.hin_gs; a.hsb += dsel * a.hin_gs;
+            a.wpk += dsel * a.w_gs;
+            a.gx += dsel * a.gx_gs;
+            a.cstate += dsel * a.c_gs;
+            a.hout += dsel * a.ho_gs;
+        }
+        BDE_TRY(lstm_sb_step_launch(a, one_dir ? 1 : 2, s));
+    }
+    return BDE_OK;
 }
 
 static int run_recurrent_steps_sb(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
@@ -1519,6 +1616,8 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     if (!enc_done && !(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, l, in, 0, (int)TB, T, B, H, W, s));
     if (!m->cfg.use_rc) return BDE_OK;
     if (m->cfg.recurrent_type == 1) return run_gru_steps(m, l, T, B, h, w, s);
+    if ((size_t)l < m->lstm_sbk.size()) m->lstm_sbk[l].sb_used = ws.hsk[l] != nullptr ? 1 : 0;
+    if (!(m->debug_skip & 4) && ws.hsk[l] != nullptr) return run_recurrent_steps_sbk(m, l, T, B, h, w, s);
     if (!(m->debug_skip & 4) && ws.hsb[l] != nullptr) {
         BDE_REQUIRE(m->dir_mask == 3, "the split-bf16 recurrent step (lstm_sb) runs both directions only");
         return run_recurrent_steps_sb(m, l, T, B, h, w, s);
@@ -2498,6 +2597,12 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_sbk") {
+        if (m->use_lstm_sbk != (int)value)
+            for (auto& w : m->wslots) w.release();
+        m->use_lstm_sbk = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "lstm_sb") {
         if (m->lstm_sb_mode != (int)value)
             for (auto& w : m->wslots) w.release();
@@ -2536,6 +2641,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "wide") *value = m->wide;
     else if (k == "conv_sb") *value = m->conv_sb;
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;
+    else if (k == "lstm_sbk") *value = m->use_lstm_sbk;
     else if (k == "packed_numel") *value = m->dev_numel;
     else if (k.compare(0, 3, "sb_") == 0 && k.size() >= 5 && k.back() >= '0' && k.back() - '0' < m->L) {
         // did the latest launch of that layer run as split bf16 (conv_sb.h)?  "sb_enc<l>", "sb_gx<l>", "sb_dec<j>"
@@ -2544,6 +2650,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
         if (what == "enc") *value = m->enc[i].sb_used;
         else if (what == "gx") *value = m->gx[i].sb_used;
         else if (what == "dec") *value = m->dec[i].sb_used;
+        else if (what == "lstm") *value = (size_t)i < m->lstm_sbk.size() ? m->lstm_sbk[i].sb_used : 0;
         else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);
     }
     else return fail(BDE_ERR_ARG, "unknown info key '%s'", key);

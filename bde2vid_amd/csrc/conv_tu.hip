@@ -11,6 +11,7 @@
 #include "conv_vec.h"
 #include "conv_sb.h"
 #include "lstm16.h"
+#include "lstm_sb.h"
 #include "pw_gemm.h"
 
 namespace bde {

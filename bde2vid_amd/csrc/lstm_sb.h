@@ -1,0 +1,346 @@
+// Recurrent ConvLSTM step with fp32-equivalent arithmetic on the bf16 matrix cores (conv_sb.h's three-term split, six
+// v_mfma_f32_32x32x16_bf16 per fp32 block) AND the pointwise tail in the epilogue -- the kernel on the sequential critical path
+// of every level (V5.py:122-135; ConvLSTM.forward, submodules.py:293-334).
+//
+//   gates[4][Ch] = conv3x3(h_prev; W[:, C:]) + gx  (gx = x-part incl. bias, batched over T by conv_sb.h);
+//   i, f, o = sigmoid, g = tanh;  c = f c + i g;  h = o tanh(c)            (chunk order i, f, o, g, :320-332)
+//
+// lstm16.h runs this step on the fp32 matrix cores: 6.5 GFLOP per step at 64 FLOP/clk/SIMD is 100 k cycles when perfectly
+// balanced (46-50 us); it measures 67 us.  On the bf16 cores the same contraction is 37 k cycles of MFMA per SIMD; what decides
+// the step then is (a) every SIMD getting the same number of MFMAs, (b) the weights -- 28 MB of split terms at level 2 -- crossing
+// the L2 -> CU path few times, (c) no second launch for the pointwise half.  A level's step is therefore cut to ONE work shape,
+//   a wave = 32 gate rows x (NT x 32) pixels x a quarter .. all of K,        432 (NT = 2) or 648 (NT = 3) MFMAs,
+// by choosing, per level, how the four waves of a workgroup divide rows and K:
+//   RTW x KW = 4:  RTW row tiles of 32 (weights differ per wave) x KW parts of K (waves of a row tile split the channel chunks
+//   and are summed through LDS).  Config A, 184 x 240:  level 0: 4 x 1, NT 2 (692 workgroups, 3 per CU);  level 1: 2 x 2, NT 2
+//   (704, 3 per CU);  level 2: 1 x 4, NT 3 = three image rows (512, 2 per CU): 1296 MFMAs per SIMD at every level, each weight
+//   fragment used for 64-96 pixels, weights read 226-311 MB per step from L2.
+//
+// Rows are packed GATE-INTERLEAVED: row 8 q + 4 hl + gate of a 32-row tile = that gate of hidden channel 8 tile + 4 hl + q, so the
+// four gates of a (channel, pixel) are four consecutive accumulator registers of one lane (acc_row: rows 8 (r >> 2) + 4 (lane >> 5)
+// + (r & 3)), a lane's four register groups are four CONSECUTIVE channels (one 8-byte store per term into the SB16 staging), and
+// c / h are finished in registers.  h leaves as fp32 planes (the level's output sequence) and as the SB16 image the next
+// step's convolution reads, assembled through LDS into 16-byte pieces.
+//
+// Operands as in conv_sb.h: h_prev SB16 [B][C/16][H][W][3 terms][16 ch] bf16, halo tiles staged by LDS-DMA at a 112-byte pixel
+// pitch (one tile per K part and stage); weights [row tile][chunk][tap][term][64 lanes][8] L2 -> registers, two taps ahead.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_sb.h"
+#include "lstm16.h"
+
+namespace bde {
+
+struct LstmSbArgs {
+    const unsigned char* hin;       // SB16 image of h_prev, group g, frame n: hin + g * hin_gs + n * hin_ns (bytes)
+    long hin_gs, hin_ns;
+    const unsigned short* wpk;      // split weights [G][row tile][chunk][tap][3][64][8]
+    long w_gs;                      // in bf16 elements
+    const float* gx;                // x-part of the gates incl. bias, gate-major [4 Ch][HW]: gx + g * gx_gs + n * gx_ns
+    long gx_gs, gx_ns;
+    float* cstate;                  // [G][B][Ch][HW], updated in place
+    long c_gs, c_ns;
+    float* hout;                    // fp32 planes [Ch][HW]: hout + g * ho_gs + n * ho_ns
+    long ho_gs, ho_ns;
+    unsigned char* hsb;             // SB16 image of h (the next step's hin), same strides as hin
+    const float* zeros;             // >= 16 bytes of zeros (source of out-of-image halo pixels)
+    int B, Ch, H, W;
+    int first;                      // 1: h_prev = c_prev = 0, no contraction
+    int TR, TC, tiles_x;            // a workgroup's pixels: TR image rows x TC columns (TR * TC <= NT * 32), tiles per row
+    unsigned long long* stamps;     // diagnostics only: s_memtime per phase, [block < 64][wave < 4][8]
+};
+#define LSB_STAMP(i)                                                                              \
+    do {                                                                                          \
+        if (a.stamps && lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)       \
+            a.stamps[(blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime();           \
+    } while (0)
+
+template <int RTW, int KW, int NT, int MAXI>
+__global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a) {
+    static_assert(RTW * KW == 4, "four waves per workgroup");
+    constexpr int QW = 4 / KW;                          // register groups (= hidden channels x 2) a wave finishes per tile
+    extern __shared__ __align__(16) unsigned char lsb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rtl = wave / KW, kp = wave - rtl * KW;    // this wave's row tile inside the workgroup and its part of K
+    const int hl = lane >> 5;
+    const int z = blockIdx.z;
+    const int g = z / a.B, n = z - g * a.B;
+    const int HW = a.H * a.W;
+    const int C16 = a.Ch / 16, nrt = a.Ch / 8;          // 16-channel chunks of K; 32-row tiles (8 hidden channels each)
+    const int rt = blockIdx.y * RTW + rtl;
+    const bool rt_live = rt < nrt;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int y0 = ty * a.TR, x0 = tx * a.TC;
+    const int tc = min(a.TC, a.W - x0), tr = min(a.TR, a.H - y0);   // live extent of this tile
+    const int IW = a.TC + 2, IR = a.TR + 2;
+    LSB_STAMP(0);
+
+    // this lane's pixel of each 32-pixel tile: q = t * 32 + (lane & 31) -> (row q / TC, column q % TC)
+    const float inv_tc = 1.0f / (float)a.TC;
+    int boff[NT], pix[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = t * 32 + (lane & 31);
+        const int py = (int)(((float)q + 0.5f) * inv_tc), px = q - py * a.TC;
+        const bool ok = py < tr && px < tc;
+        pix[t] = ok ? (y0 + py) * a.W + x0 + px : -1;
+        const int cy = min(py, a.TR - 1), cx = min(px, a.TC - 1);   // (dead lanes read inside the tile)
+        boff[t] = (cy * IW + cx) * SB_LDS_PITCH + hl * 16;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // pointwise operands of the (channel, pixel)s this wave finishes: register groups q = kp * QW .. + QW - 1 of its row tile
+    float gv[NT][QW][4], cprev[NT][QW];
+    const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
+    float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
+    auto epi_load = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq) {
+                const int hc = min(rt * 8 + 4 * hl + kp * QW + qq, a.Ch - 1);
+                const long o = (long)hc * HW + max(pix[t], 0);
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) gv[t][qq][gate] = gxb[(long)gate * a.Ch * HW + o];
+                cprev[t][qq] = a.first ? 0.f : cst[o];
+            }
+    };
+
+    const int stages = C16 / KW;                         // chunks per part of K
+    const int nslots = IR * IW * 7;                      // 16-byte slots of one halo tile (6 of data + the pad slot per pixel)
+    const int nblk = (nslots + 63) >> 6;                 // 1-KiB DMA blocks of one tile
+    const int tile_bytes = nblk * 1024;
+    if (a.first) {
+        epi_load();
+    } else {
+        const unsigned char* inb = a.hin + g * a.hin_gs + n * a.hin_ns;
+        const long plane = (long)HW * SB_PIX_BYTES;
+        // halo staging: KW tiles per stage (one per part of K), KW * nblk blocks dealt to the four waves
+        unsigned goff[MAXI];
+        const float inv_iw = 1.0f / (float)IW, inv_nblk = 1.0f / (float)nblk;
+        unsigned vmask = 0;
+        unsigned long long pmask = 0;                    // two bits per block of this wave = the part of K the block belongs to
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int blk = wave + it * 4;
+            const int part = (int)(((float)blk + 0.5f) * inv_nblk), b_in = blk - part * nblk;
+            const int i = b_in * 64 + lane;
+            const int px = i / 7, qs = i - px * 7;
+            const int r = (int)(((float)px + 0.5f) * inv_iw), c = px - r * IW;      // (exact for px < 2^20; an integer division by a
+            const int iy = y0 - 1 + r, ix = x0 - 1 + c;                           //  run-time divisor is ~40 instructions, MAXI times)
+            const bool ok = part < KW && i < nslots && qs < 6 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            goff[it] = ok ? (unsigned)((iy * a.W + ix) * SB_PIX_BYTES + qs * 16) : 0u;
+            if (ok) vmask |= 1u << it;
+            pmask |= (unsigned long long)(part & 3) << (2 * it);
+        }
+        const unsigned char* zero16 = reinterpret_cast<const unsigned char*>(a.zeros);
+        auto stage = [&](int s) {
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) {
+                const int blk = wave + it * 4;
+                if (blk < KW * nblk) {
+                    const int part = (int)((pmask >> (2 * it)) & 3ull);
+                    const unsigned char* src = ((vmask >> it) & 1u) ? inb + (long)(part * stages + s) * plane + goff[it] : zero16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lsb + blk * 1024), 16, 0, 0);
+                }
+            }
+        };
+        // weight fragments of this wave: row tile rt, chunks kp * stages .. + stages - 1 (consecutive in memory)
+        constexpr int TAPS = 9, RING = 3, PF = 2;
+        const int S = stages * TAPS;
+        const sb8* wfr = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) +
+                         (((long)min(rt, nrt - 1) * C16 + (long)kp * stages) * TAPS * 3) * 64 + lane;
+        sb8 af[RING][3];
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) af[q][k] = wfr[((long)min(q, S - 1) * 3 + k) * 64];
+        const unsigned char* tile = lsb + kp * tile_bytes;
+        LSB_STAMP(1);
+        for (int s = 0; s < stages; ++s) {
+            __syncthreads();                             // every wave is done with the previous stage's tiles
+            stage(s);
+            if (s == stages - 1) epi_load();             // the tail's operands travel during the last stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s == 0) LSB_STAMP(2);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int cur = tap % RING, nxt = (tap + PF) % RING;
+                {
+                    const long sp = min(s * TAPS + tap + PF, S - 1);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) af[nxt][k] = wfr[(sp * 3 + k) * 64];
+                }
+                const int ky = tap / 3, kx = tap - ky * 3;
+                sb8 bfr[NT][3];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    // small terms first, the leading product last
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[t][2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][2], bfr[t][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bfr[t][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[t][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bfr[t][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[t][0], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        LSB_STAMP(3);
+        __syncthreads();                                 // the halo tiles are dead: LDS becomes the reduction / output staging area
+    }
+    LSB_STAMP(4);
+
+    // ---- sum over the parts of K: every wave leaves its accumulators in LDS, wave (row tile, kp) collects register groups
+    //      kp * QW .. of its row tile from the KW waves of that row tile -----------------------------------------------------
+    float gsum[NT][QW][4];
+    if (KW > 1 && !a.first) {
+        float* red = reinterpret_cast<float*>(lsb);      // [wave][tile][reg][64 lanes]
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq)
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int p = 0; p < KW; ++p) s += red[(((rtl * KW + p) * NT + t) * 16 + 4 * (kp * QW + qq) + gate) * 64 + lane];
+                    gsum[t][qq][gate] = s;
+                }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq)
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) gsum[t][qq][gate] = acc[t][4 * (kp * QW + qq) + gate];
+    }
+
+    LSB_STAMP(5);
+    // ---- pointwise tail (submodules.py:320-332) and the outputs -----------------------------------------------------------------
+    // h as SB16 goes through LDS: [row tile of the workgroup][pixel of the tile][term][8 channels] bf16, 16-byte pieces out
+    unsigned short* hst = reinterpret_cast<unsigned short*>(lsb);
+    float* hob = a.hout + g * a.ho_gs + n * a.ho_ns;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        unsigned short t3[QW][3];
+        const bool live = rt_live && pix[t] >= 0;
+#pragma unroll
+        for (int qq = 0; qq < QW; ++qq) {
+            const int hc = rt * 8 + 4 * hl + kp * QW + qq;   // hidden channel: 4 hl + (register group) inside the row tile
+            const float vi = gsum[t][qq][0] + gv[t][qq][0], vf = gsum[t][qq][1] + gv[t][qq][1];
+            const float vo = gsum[t][qq][2] + gv[t][qq][2], vg = gsum[t][qq][3] + gv[t][qq][3];
+            const float c = sigmoid_fast(vf) * cprev[t][qq] + sigmoid_fast(vi) * tanh_fast(vg);
+            const float h = sigmoid_fast(vo) * tanh_fast(c);
+            if (live) {
+                const long o = (long)hc * HW + pix[t];
+                cst[o] = c;
+                hob[o] = h;
+            }
+            sb_split3_dev(live ? h : 0.f, t3[qq][0], t3[qq][1], t3[qq][2]);
+        }
+        const int q = t * 32 + (lane & 31);
+        unsigned short* d = hst + ((rtl * (NT * 32) + q) * 3) * 8 + 4 * hl + kp * QW;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (QW == 4) *reinterpret_cast<uint2*>(d + k * 8) = uint2{t3[0][k] | ((unsigned)t3[1][k] << 16), t3[2][k] | ((unsigned)t3[3][k] << 16)};
+            else if (QW == 2) *reinterpret_cast<unsigned*>(d + k * 8) = t3[0][k] | ((unsigned)t3[QW - 1][k] << 16);
+            else d[k * 8] = t3[0][k];
+        }
+    }
+    __syncthreads();
+    {
+        unsigned char* hsbo = a.hsb + g * a.hin_gs + n * a.hin_ns;
+        const int pieces = RTW * NT * 32 * 3;                // 16-byte pieces: (row tile, pixel, term)
+        for (int i = tid; i < pieces; i += 256) {
+            const int k = i % 3, r2 = i / 3;
+            const int q = r2 % (NT * 32), rl = r2 / (NT * 32);
+            const int py = q / a.TC, px = q - py * a.TC;
+            const int rtt = blockIdx.y * RTW + rl;
+            if (py >= tr || px >= tc || rtt >= nrt) continue;
+            const long p = (long)(y0 + py) * a.W + x0 + px;
+            const uint4 v = *reinterpret_cast<const uint4*>(hst + ((rl * (NT * 32) + q) * 3 + k) * 8);
+            // chunk rtt / 2, pixel p, term k, half (rtt & 1) of the 16 channels
+            *reinterpret_cast<uint4*>(hsbo + (((long)(rtt >> 1) * HW + p) * 3 + k) * 32 + (rtt & 1) * 16) = v;
+        }
+    }
+    LSB_STAMP(6);
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+struct LstmSbShape { int rtw, kw, nt, TR, TC, tiles_x, tiles_y, maxi; size_t lds; bool ok; };
+
+// How a level's step is cut (see the header): KW parts of K per workgroup by the number of 16-channel chunks, NT by the map width.
+static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
+    LstmSbShape s{};
+    s.ok = false;
+    if (Ch % 16 != 0 || Ch < 16) return s;
+    const int C16 = Ch / 16;
+    s.kw = C16 >= 16 ? 4 : (C16 >= 8 ? 2 : 1);
+    if (C16 % s.kw != 0) s.kw = 1;
+    s.rtw = 4 / s.kw;
+    s.nt = s.kw == 4 ? 3 : 2;
+    const int px = s.nt * 32;
+    if (W >= px) { s.TR = 1; s.TC = px; }                 // row segments
+    else { s.TC = W; s.TR = std::max(1, std::min(px / W, H)); }
+    s.tiles_x = cdiv(W, s.TC);
+    s.tiles_y = cdiv(H, s.TR);
+    const long halo = (long)(s.TR + 2) * (s.TC + 2);
+    const long nblk = (halo * 7 + 63) / 64;
+    const long blocks = nblk * s.kw;
+    s.maxi = (int)((blocks + 3) / 4);
+    const size_t stage_b = (size_t)blocks * 1024;
+    const size_t red_b = s.kw > 1 ? (size_t)4 * s.nt * 16 * 64 * 4 : 0;
+    const size_t hst_b = (size_t)s.rtw * s.nt * 32 * 3 * 16;
+    s.lds = std::max(stage_b, std::max(red_b, hst_b));
+    s.ok = s.maxi <= 24 && s.lds <= 80 * 1024;
+    return s;
+}
+
+#ifdef BDE_CONV_TU
+template <int RTW, int KW, int NT, int MAXI>
+static int lstm_sb_launch_t(const LstmSbArgs& a, const LstmSbShape& s, int G, hipStream_t stream) {
+    auto kern = lstm_sb_step_kernel<RTW, KW, NT, MAXI>;
+    static unsigned char raised[BDE_MAX_DEVICES];
+    if (s.lds > 64 * 1024) BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
+    dim3 grid(s.tiles_x * s.tiles_y, cdiv(a.Ch / 8, RTW), G * a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), s.lds, stream, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+template <int RTW, int KW, int NT>
+static int lstm_sb_launch_m(const LstmSbArgs& a, const LstmSbShape& s, int G, hipStream_t stream) {
+    if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6>(a, s, G, stream);
+    if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12>(a, s, G, stream);
+    return lstm_sb_launch_t<RTW, KW, NT, 24>(a, s, G, stream);
+}
+int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream) {
+    const LstmSbShape s = lstm_sb_shape(a.Ch, a.H, a.W);
+    if (!s.ok) return fail(BDE_ERR_UNSUPPORTED, "split-bf16 recurrent step: no shape for %d channels on a %dx%d map", a.Ch, a.H, a.W);
+    a.TR = s.TR; a.TC = s.TC; a.tiles_x = s.tiles_x;
+    if (s.kw == 4) return lstm_sb_launch_m<1, 4, 3>(a, s, G, stream);
+    if (s.kw == 2) return lstm_sb_launch_m<2, 2, 2>(a, s, G, stream);
+    return lstm_sb_launch_m<4, 1, 2>(a, s, G, stream);
+}
+#else
+int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream);   // conv_tu.hip
+#endif
+
+}  // namespace bde

@@ -163,7 +163,7 @@ class Work:
 
 KERNEL_OF_SPAN = [
     # span name pattern -> (regex on the rocprofv3 kernel name, readable description)
-    (r'lstm(\d)', r'lstm16_step_kernel', 'recurrent ConvLSTM step of level {0}, both directions (csrc/lstm16.h)'),
+    (r'lstm(\d)', r'lstm_sb_step_kernel|lstm16_step_kernel', 'recurrent ConvLSTM step of level {0}, both directions, pointwise tail fused (csrc/lstm_sb.h: split bf16; csrc/lstm16.h where no shape fits)'),
     (r'winblock(\d)', r'winblock_kernel', 'one temporal window-attention block of level {0} per launch (csrc/winblock.h)'),
     (r'wideblock(\d)', r'wideblock_', 'temporal window-attention block of level {0} (csrc/wideblock.h)'),
     (r'gates_x(\d)', r'conv_sb_kernel<3, 1|conv_vec_kernel<3, 1', 'x-part of the ConvLSTM gates of level {0}, 3x3 conv batched over T, both directions (csrc/conv_sb.h; conv_vec.h when no split-bf16 shape fits)'),
@@ -472,10 +472,10 @@ def main():
         fwd_ms = spans.get('forward', (0.0, 0))[0] / max(n_eager, 1)
         # spans whose contraction ran as split bf16 (csrc/conv_sb.h; the library says which: bde_get_info "sb_gx<l>" / "sb_enc<l>" /
         # "sb_dec<j>"; spans include the SB16 conversion of the input)
-        sb_key = {'gates_x': 'sb_gx', 'enc_conv': 'sb_enc', 'dec_conv': 'sb_dec'}
+        sb_key = {'gates_x': 'sb_gx', 'enc_conv': 'sb_enc', 'dec_conv': 'sb_dec', 'lstm': 'sb_lstm'}
         for nm, k in kernels.items():
             k['share'] = k['ms_per_forward'] / fwd_ms if fwd_ms > 0 else None
-            mm = re.fullmatch(r'(gates_x|enc_conv|dec_conv)(\d)', nm)
+            mm = re.fullmatch(r'(gates_x|enc_conv|dec_conv|lstm)(\d)', nm)
             split = bool(mm) and model.get_info(sb_key[mm.group(1)] + mm.group(2)) == 1     # what the library launched
             k['peak'] = SPLIT_BF16_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
             if split:

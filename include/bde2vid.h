@@ -130,6 +130,10 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *              range of (frame, pixel tile, channel group); 0 = plain grid order.  Same results.
  *   "fuse_enc_sb": 1 (default) lets an encoder convolution store its result only as the split-bf16 image its gate
  *              convolution reads; 0 writes fp32 planes and converts them in a pass of their own (same frames, bit for bit).
+ *   "lstm_sbk": 1 (default) runs the recurrent ConvLSTM step on the bf16 matrix cores with three-term split operands and the
+ *              pointwise tail fused (csrc/lstm_sb.h: fp32-equivalent) wherever a shape fits; 0 = the fp32 matrix-core step (lstm16.h).
+ *   "winblock_sb": 1 (default) runs the four GEMM phases of that one-launch block on the bf16 matrix cores, three-term split
+ *              operands (csrc/winblock_sb.h: fp32-equivalent); 0 = fp32 MFMAs throughout (winblock.h).
  *   "winblock": 1 (default) runs an attention block of a 64-channel / 16-head level as ONE launch
  *               (csrc/winblock.h); 0 keeps the split path (attention core + fused token kernel).
  *   "attn_mfma": 1 (default) uses the matrix-core attention core for head_dim 16 (csrc/attn_mfma.h).
@@ -139,8 +143,9 @@ int bde_wait_outputs(bde_model* m, void* stream);
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 /* Read back the state the measurement has to be honest about: "debug_skip" (non-zero = stages skipped, results
  * invalid), "graph" (0 also after a failed capture), "graphs_live" (workspaces replaying a captured launch
- * sequence), "pipeline", "winblock", "wide", "conv_sb", "lstm_sb", "last_stream", "device", "packed_numel"; and which
- * convolutions the latest forward ran as split bf16 (csrc/conv_sb.h): "sb_enc<l>", "sb_gx<l>", "sb_dec<j>" (0 / 1).
+ * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "lstm_sb", "lstm_sbk", "last_stream", "device", "packed_numel"; and which
+ * convolutions the latest forward ran as split bf16 (csrc/conv_sb.h): "sb_enc<l>", "sb_gx<l>", "sb_dec<j>" (0 / 1), and
+ * "sb_lstm<l>": the recurrent steps of level l ran on the fused split-bf16 step kernel (csrc/lstm_sb.h).
  * Settings are per model object. */
 int bde_get_info(const bde_model* m, const char* key, int64_t* value);
 
