@@ -288,13 +288,12 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 struct LstmSbShape { int rtw, kw, nt, TR, TC, tiles_x, tiles_y, maxi; size_t lds; bool ok; };
 
 // How a level's step is cut (see the header): KW parts of K per workgroup by the number of 16-channel chunks, NT by the map width.
-static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
+static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw) {
     LstmSbShape s{};
     s.ok = false;
-    if (Ch % 16 != 0 || Ch < 16) return s;
     const int C16 = Ch / 16;
-    s.kw = C16 >= 16 ? 4 : (C16 >= 8 ? 2 : 1);
-    if (C16 % s.kw != 0) s.kw = 1;
+    if (C16 % kw != 0) return s;
+    s.kw = kw;
     s.rtw = 4 / s.kw;
     s.nt = s.kw == 4 ? 3 : 2;
     const int px = s.nt * 32;
@@ -310,8 +309,21 @@ static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
     const size_t red_b = s.kw > 1 ? (size_t)4 * s.nt * 16 * 64 * 4 : 0;
     const size_t hst_b = (size_t)s.rtw * s.nt * 32 * 3 * 16;
     s.lds = std::max(stage_b, std::max(red_b, hst_b));
-    s.ok = s.maxi <= 24 && s.lds <= 80 * 1024;
+    s.ok = s.maxi <= 24 && s.lds <= 80 * 1024;            // (two workgroups per CU at least)
     return s;
+}
+static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
+    LstmSbShape none{};
+    none.ok = false;
+    if (Ch % 16 != 0 || Ch < 16) return none;
+    const int C16 = Ch / 16;
+    // the more chunks of K, the more of them a workgroup's waves split; a map whose rows do not fill the wider tile of the
+    // four-way split (LDS of its four halo tiles) falls back to the next shape
+    for (int kw = C16 >= 16 ? 4 : (C16 >= 8 ? 2 : 1); kw >= 1; kw >>= 1) {
+        const LstmSbShape s = lstm_sb_shape_kw(Ch, H, W, kw);
+        if (s.ok) return s;
+    }
+    return none;
 }
 
 #ifdef BDE_CONV_TU
