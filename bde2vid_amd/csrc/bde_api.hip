@@ -691,6 +691,7 @@ struct bde_model {
     int winblock_sb = 1;          // ... with its GEMM phases on the bf16 matrix cores, three-term split operands (winblock_sb.h)
     int fuse_pred = 1;            // predI + sigmoid in the last decoder conv's epilogue
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
+    int wide_fuse_qkv = 1;        // ... with the query frame's q | k | v computed inside the attention core (no GEMM launch of its own)
     int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
     int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
     int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
@@ -1892,11 +1893,21 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
         const bool dil = (i % 2) == 1;                       // DTransformer.py:362
         const bool last = (i == blk0 + nblk - 1);
         const float* qkv = ws.qkv;
-        if (i == blk0 && qkv_first) qkv = qkv_first;
+        const bool fuse_qkv = m->wide_fuse_qkv != 0;       // q | k | v of the query frame inside the attention core (wideblock.h)
+        if (fuse_qkv) qkv = nullptr;
+        else if (i == blk0 && qkv_first) qkv = qkv_first;
         else BDE_TRY(run_tokgemm(m, "wide_qkv", l, ab.qkvW, ab.qkv, 3 * C, C, x, B, HW, ws.qkv, nullptr, ACT_NONE, nullptr, nullptr,
                                  nullptr, 0, 0, 0, 0, s));
         AttnTokArgs a;
         memset(&a, 0, sizeof a);
+        if (fuse_qkv) {
+            a.x = x;
+            a.x_bs = (long)ntile * 16 * C;
+            a.wqkv = m->P(ab.qkvW);
+            a.bqkv = m->P(ab.qkv.b_off);
+            a.sqkv = m->P(ab.qkv.s_off);
+            a.q_slot = c.q_idx;
+        }
         a.q = qkv;
         a.q_bs = HW * 3 * C;
         a.q_ld = 3 * C;
@@ -1970,8 +1981,9 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         if (need_un)
             BDE_TRY(run_tokgemm(m, "wide_kv_all", l, al.kvallW, al.kvall, al.depth * 2 * C, C, ws.mergedT[l], T * B, HW, ws.kvun[l],
                                 nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
-        BDE_TRY(run_tokgemm(m, "wide_qkv_all", l, al.blocks[0].qkvW, al.blocks[0].qkv, 3 * C, C, ws.mergedT[l], T * B, HW, ws.qkv0[l],
-                            nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+        if (!m->wide_fuse_qkv)
+            BDE_TRY(run_tokgemm(m, "wide_qkv_all", l, al.blocks[0].qkvW, al.blocks[0].qkv, 3 * C, C, ws.mergedT[l], T * B, HW, ws.qkv0[l],
+                                nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
         for (int t = 0; t < T; ++t) {
             const float* kvslot[BDE_MAX_FRAMES];
             for (int d = 0; d < D; ++d) {
@@ -2594,6 +2606,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         m->wide = (int)value;
         return BDE_OK;
     }
+    if (std::string(key) == "wide_fuse_qkv") { m->wide_fuse_qkv = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }

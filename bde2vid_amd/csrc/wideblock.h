@@ -349,11 +349,24 @@ struct AttnTokArgs {
     float* out;                   // FRAG16 [B][ntile][C/16][256]
     long out_bs;
     int D, C, heads, H, W, Hp, Wp, pt, pl, nWw, dilated, ntile;
+    // FUSE: q | k | v of the query frame are computed here from the block input instead of read from `q` / kv[q_slot]
+    const float* x;               // FRAG16 [B][ntile][C/16][256]: the block input (current x of the query frame)
+    long x_bs;
+    const float* wqkv;            // packed as for tokgemm_kernel: [3C/16][C/16][256]; rows q | k | v, LayerNorms folded
+    const float* bqkv;            // [3C] folded biases
+    const float* sqkv;            // [3C] row sums of the folded weights
+    int q_slot;                   // buffer slot of the query frame
 };
 
 // softmax(q k^T + bias) v for one (window, head), head_dim 16; four waves = four tiles of 16 queries (attn_mfma.h).
 // The 16 channels of the head are contracted in the order (4 g4 + ks): a lane's 16-byte load of q is then its four
 // B-operand values as they stand, and K is staged into LDS rows in the same order.
+// FUSE: the workgroup first computes q | k | v of its head for the window's 49 tokens of the query frame -- three row tiles of the
+// q|k|v GEMM, K = C, wave = token tile, operand fragments gathered straight from the FRAG16 block input (a window token's
+// fragment is one 16-byte load per lane and channel group) -- instead of a GEMM launch of its own in front of this one
+// (8.9 us on the sequential chain for 0.36 GFLOP).  The D fragments ARE what the attention wants: q as the score MFMA's B
+// operand, K and V as the LDS rows below; the per-(window, head) split repeats no work.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
     constexpr int HD = 16, NT = 10;
     __shared__ __align__(16) float KL[NT * HD * 16];
@@ -373,7 +386,66 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
     };
     const int qi = wave * 16 + col;
     const int qpix = qi < ATT_TOK ? token_pixel(qi) : -1;
-    wf4 qv = *reinterpret_cast<const wf4*>(a.q + b * a.q_bs + (long)max(qpix, 0) * a.q_ld + c0 + 4 * g4);
+    wf4 qv;
+    if constexpr (FUSE) {
+        // rows head (q), C/16 + head (k), 2C/16 + head (v) of the packed q|k|v weights; this wave's token tile = queries 16 wave ..
+        const int ngk = a.C >> 4;
+        const wf4* xw = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)(max(qpix, 0) >> 4) * ngk) * 64 + (max(qpix, 0) & 15) + 16 * g4;
+        const wf4* wq = reinterpret_cast<const wf4*>(a.wqkv) + ((long)head * ngk) * 64 + lane;
+        const wf4* wk = reinterpret_cast<const wf4*>(a.wqkv) + ((long)(ngk + head) * ngk) * 64 + lane;
+        const wf4* wv = reinterpret_cast<const wf4*>(a.wqkv) + ((long)(2 * ngk + head) * ngk) * 64 + lane;
+        f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
+        float s1 = 0.f, s2 = 0.f;
+        const bool any = wave * 16 < ATT_TOK;                      // (tile 3 holds token 48 only; a tile past the window is skipped)
+        if (any) {
+            constexpr int U = 4;
+#pragma unroll 1
+            for (int kg = 0; kg < ngk; kg += U) {
+                wf4 xb[U], fq[U], fk[U], fv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xb[u] = xw[(long)(kg + u) * 64];
+                    fq[u] = wq[(long)(kg + u) * 64];
+                    fk[u] = wk[(long)(kg + u) * 64];
+                    fv[u] = wv[(long)(kg + u) * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wf4 xx = xb[u];
+                    if (qpix < 0) xx = wf4{0.f, 0.f, 0.f, 0.f};    // a zero token: LayerNorm(0) = beta, i.e. the folded bias alone
+                    s1 += (xx[0] + xx[1]) + (xx[2] + xx[3]);
+                    s2 += (xx[0] * xx[0] + xx[1] * xx[1]) + (xx[2] * xx[2] + xx[3] * xx[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        aq = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[u][j], xx[j], aq, 0, 0, 0);
+                        ak = __builtin_amdgcn_mfma_f32_16x16x4f32(fk[u][j], xx[j], ak, 0, 0, 0);
+                        av = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[u][j], xx[j], av, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        const float mean = s1 / (float)a.C;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(s2 / (float)a.C - mean * mean, 0.f) + 1e-5f);
+        float kq[4], vq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rq = c0 + 4 * g4 + r, rk = a.C + rq, rv = 2 * a.C + rq;
+            qv[r] = rstd * (aq[r] - mean * a.sqkv[rq]) + a.bqkv[rq];
+            kq[r] = rstd * (ak[r] - mean * a.sqkv[rk]) + a.bqkv[rk];
+            vq[r] = rstd * (av[r] - mean * a.sqkv[rv]) + a.bqkv[rv];
+        }
+        if (qi < ATT_TOK) {
+            // key index of this token in the slot-major key order; K row (k-step e = r, lanes g4) and the V row of the core below
+            const int u = a.q_slot * ATT_TOK + qi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) KL[((u >> 4) * HD + r * 4 + g4) * 16 + (u & 15)] = kq[r];
+            *reinterpret_cast<wf4*>(VL + u * HD + g4 * 4) = wf4{vq[0], vq[1], vq[2], vq[3]};
+        }
+    } else {
+        qv = *reinterpret_cast<const wf4*>(a.q + b * a.q_bs + (long)max(qpix, 0) * a.q_ld + c0 + 4 * g4);
+    }
     if (qpix < 0) qv = wf4{0.f, 0.f, 0.f, 0.f};
     const float* bias = a.biasT + (long)head * nkey * ATT_TOK + min(qi, ATT_TOK - 1);
     f32x4 sc[NT];
@@ -393,7 +465,7 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
             const int u = it >> 2, cg = it & 3;
             const int d = min(u / ATT_TOK, a.D - 1), tok = u - (u / ATT_TOK) * ATT_TOK;
             const int pix = u < nkey ? token_pixel(tok) : -1;
-            const float* kp = u < nkey ? a.kv[d] : nullptr;
+            const float* kp = (u < nkey && !(FUSE && d == a.q_slot)) ? a.kv[d] : nullptr;
             const bool use = pix >= 0 && kp != nullptr;
             const float* ksrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.k_off[d] + c0 + cg * 4 : a.kvpad + c0 + cg * 4;
             const float* vsrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.v_off[d] + c0 + cg * 4 : a.kvpad + a.C + c0 + cg * 4;
@@ -403,7 +475,7 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int it = tid + t * 256;
-            if (it < NT * 16 * 4) {
+            if (it < NT * 16 * 4 && !(FUSE && (it >> 2) / ATT_TOK == a.q_slot)) {     // (fused: the query frame's rows are written above)
                 const int u = it >> 2, cg = it & 3;
                 // channel cg*4 + e of the head is contracted at k-step e by the lanes g4 = cg: LDS row e*4 + cg
 #pragma unroll
@@ -453,7 +525,8 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
 
 static int attn_tok16_launch(const AttnTokArgs& a, int B, hipStream_t s) {
     const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
-    hipLaunchKernelGGL(attn_tok16_kernel, dim3(nW, a.heads, B), dim3(256), 0, s, a);
+    if (a.x) hipLaunchKernelGGL(attn_tok16_kernel<true>, dim3(nW, a.heads, B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn_tok16_kernel<false>, dim3(nW, a.heads, B), dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }

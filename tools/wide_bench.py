@@ -19,17 +19,22 @@ m.set_tuning('wide', 0)
 y_old = ops.dframe_attention(m, 2, bufs)
 m.set_tuning('wide', 1)
 print('max |wide - split path| over 6 blocks:', float((y - y_old).abs().max()))
-L.bde_profile_reset(m._h, 1)
-for _ in range(20):
-    ops.dframe_attention(m, 2, bufs)
-torch.cuda.synchronize()
-buf = C.create_string_buffer(4096)
-L.bde_profile_names(m._h, buf, len(buf))
-tot = 0.0
-for nm in buf.value.decode().split():
-    ms, cnt = C.c_double(), C.c_int64()
-    L.bde_profile_get(m._h, nm.encode(), C.byref(ms), C.byref(cnt))
-    per_frame = ms.value / 20 * 1e3
-    tot += per_frame
-    print(f'{nm:16s} {cnt.value // 20:3d} launches/frame  {ms.value / cnt.value * 1e3:7.2f} us each  {per_frame:8.1f} us/frame')
-print(f'sum of spans per frame: {tot:.1f} us (eager, HIP events incl. their overhead)')
+for fuse in (0, 1):
+    m.set_tuning('wide_fuse_qkv', fuse)
+    yf = ops.dframe_attention(m, 2, bufs)
+    print(f'wide_fuse_qkv={fuse}: max |y - split path| {float((yf - y_old).abs().max()):.3e}')
+    L.bde_profile_reset(m._h, 1)
+    for _ in range(20):
+        ops.dframe_attention(m, 2, bufs)
+    torch.cuda.synchronize()
+    buf = C.create_string_buffer(4096)
+    L.bde_profile_names(m._h, buf, len(buf))
+    tot = 0.0
+    for nm in buf.value.decode().split():
+        ms, cnt = C.c_double(), C.c_int64()
+        L.bde_profile_get(m._h, nm.encode(), C.byref(ms), C.byref(cnt))
+        per_frame = ms.value / 20 * 1e3
+        tot += per_frame
+        print(f'  {nm:16s} {cnt.value // 20:3d} launches/frame  {ms.value / cnt.value * 1e3:7.2f} us each  {per_frame:8.1f} us/frame')
+    print(f'  sum of spans per frame: {tot:.1f} us (eager, HIP events incl. their overhead)')
+    L.bde_profile_reset(m._h, 0)
