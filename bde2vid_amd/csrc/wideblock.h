@@ -398,30 +398,39 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
         float s1 = 0.f, s2 = 0.f;
         const bool any = wave * 16 < ATT_TOK;                      // (tile 3 holds token 48 only; a tile past the window is skipped)
         if (any) {
+            // two register buffers of U channel groups (literal indices only): the next batch of operand fragments is in flight
+            // during the MFMAs of the current one -- a workgroup has the CU almost to itself, nobody else covers an L2 round trip
             constexpr int U = 4;
-#pragma unroll 1
-            for (int kg = 0; kg < ngk; kg += U) {
-                wf4 xb[U], fq[U], fk[U], fv[U];
+            wf4 xb[2][U], fq[2][U], fk[2][U], fv[2][U];
+            auto fetch = [&](int buf, int kg) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    xb[u] = xw[(long)(kg + u) * 64];
-                    fq[u] = wq[(long)(kg + u) * 64];
-                    fk[u] = wk[(long)(kg + u) * 64];
-                    fv[u] = wv[(long)(kg + u) * 64];
+                    const long o = (long)min(kg + u, ngk - 1) * 64;
+                    xb[buf][u] = xw[o]; fq[buf][u] = wq[o]; fk[buf][u] = wk[o]; fv[buf][u] = wv[o];
                 }
+            };
+            auto compute = [&](int buf, int kg) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    wf4 xx = xb[u];
+                    if (kg + u >= ngk) continue;
+                    wf4 xx = xb[buf][u];
                     if (qpix < 0) xx = wf4{0.f, 0.f, 0.f, 0.f};    // a zero token: LayerNorm(0) = beta, i.e. the folded bias alone
                     s1 += (xx[0] + xx[1]) + (xx[2] + xx[3]);
                     s2 += (xx[0] * xx[0] + xx[1] * xx[1]) + (xx[2] * xx[2] + xx[3] * xx[3]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        aq = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[u][j], xx[j], aq, 0, 0, 0);
-                        ak = __builtin_amdgcn_mfma_f32_16x16x4f32(fk[u][j], xx[j], ak, 0, 0, 0);
-                        av = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[u][j], xx[j], av, 0, 0, 0);
+                        aq = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[buf][u][j], xx[j], aq, 0, 0, 0);
+                        ak = __builtin_amdgcn_mfma_f32_16x16x4f32(fk[buf][u][j], xx[j], ak, 0, 0, 0);
+                        av = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[buf][u][j], xx[j], av, 0, 0, 0);
                     }
                 }
+            };
+            fetch(0, 0);
+            for (int kg = 0; kg < ngk; kg += 2 * U) {
+                if (kg + U < ngk) fetch(1, kg + U);
+                compute(0, kg);
+                if (kg + 2 * U < ngk) fetch(0, kg + 2 * U);
+                if (kg + U < ngk) compute(1, kg + U);
             }
         }
         s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);

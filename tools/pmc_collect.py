@@ -17,12 +17,12 @@ import sys
 
 # bench.py span -> predicate on (kernel name, grid size): a span can share a kernel template with others; the grid tells them apart
 SPAN_KERNELS = [
-    ('winblock0', r'winblock_kernel'),
+    ('winblock0', r'winblock_sb_kernel|winblock_kernel'),
     ('wide_*(tokgemm)', r'tokgemm_kernel'),
     ('wide_core2', r'attn_tok16_kernel'),
-    ('lstm0', r'lstm16_step_kernel<1, 128, 2'),
-    ('lstm1', r'lstm16_step_kernel<1, 64, 1'),
-    ('lstm2', r'lstm16_step_kernel<2, 32, 1'),
+    ('lstm0', r'lstm_sb_step_kernel<4, 1, 2|lstm16_step_kernel<1, 128, 2'),
+    ('lstm1', r'lstm_sb_step_kernel<2, 2, 2|lstm16_step_kernel<1, 64, 1'),
+    ('lstm2', r'lstm_sb_step_kernel<1, 4, 3|lstm16_step_kernel<2, 32, 1'),
     ('gates_x*', r'conv_sb_kernel<3, 1|conv_vec_kernel<3, 1'),
     ('split_bf16', r'split_bf16_kernel'),
     ('enc_conv*', r'conv_sb_kernel<5, 2|conv_vec_kernel<5, 2'),
@@ -33,7 +33,7 @@ SPAN_KERNELS = [
     ('dec_up*', r'upsample2x_sum_kernel'),
     ('pred', r'pred_kernel'),
     ('merge*', r'add2_kernel'),
-    ('voxel_native', r'voxel_tile_kernel|voxel_scatter_native_kernel'),
+    ('voxel_native', r'voxel_tile_kernel|voxel_scatter_native_kernel|voxel_bucket_kernel|voxel_tile_from_buckets_kernel'),
 ]
 
 
