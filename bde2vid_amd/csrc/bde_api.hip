@@ -695,6 +695,10 @@ struct bde_model {
     int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
     int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
     int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
+    int lstm_two_streams = 0;     // the two sweep directions of a level as two launch chains on two streams (independent until the merge);
+                                  // measured: 1208 vs 1444 frames/s pipelined, 1135 vs 1161 single stream -- half-size launches take almost as long: off
+    hipStream_t dir_stream[4] = {};         // per workspace slot: the second direction's stream and its fork / join events
+    hipEvent_t dir_fork[4] = {}, dir_join[4] = {};
     int use_lstm_sbk = 1;         // recurrent step on the bf16 matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
@@ -1618,7 +1622,32 @@ static int run_recurrent_level(bde_model* m, int l, const float* in, int T, int 
     if (!m->cfg.use_rc) return BDE_OK;
     if (m->cfg.recurrent_type == 1) return run_gru_steps(m, l, T, B, h, w, s);
     if ((size_t)l < m->lstm_sbk.size()) m->lstm_sbk[l].sb_used = ws.hsk[l] != nullptr ? 1 : 0;
-    if (!(m->debug_skip & 4) && ws.hsk[l] != nullptr) return run_recurrent_steps_sbk(m, l, T, B, h, w, s);
+    if (!(m->debug_skip & 4) && ws.hsk[l] != nullptr) {
+        if (m->lstm_two_streams && m->dir_mask == 3 && !m->prof_on) {
+            // A step launch's workgroups run in lockstep: prologue, halo wait and the pointwise tail (a quarter of the cycles)
+            // leave the matrix cores idle chip-wide.  The forward and the backward sweep are independent until the merge
+            // (V5.py:122-147): as two chains of one-direction launches on two streams they drift apart and one direction's
+            // MFMA phases cover the other's tails.  Same launches per direction as bde_split_sweep: results are bit-identical.
+            const int slot = m->cur;
+            if (!m->dir_stream[slot]) {
+                BDE_HIP(hipStreamCreateWithFlags(&m->dir_stream[slot], hipStreamNonBlocking));
+                BDE_HIP(hipEventCreateWithFlags(&m->dir_fork[slot], hipEventDisableTiming));
+                BDE_HIP(hipEventCreateWithFlags(&m->dir_join[slot], hipEventDisableTiming));
+            }
+            hipStream_t s2 = m->dir_stream[slot];
+            BDE_HIP(hipEventRecord(m->dir_fork[slot], s));
+            BDE_HIP(hipStreamWaitEvent(s2, m->dir_fork[slot], 0));
+            m->dir_mask = 1;
+            int st = run_recurrent_steps_sbk(m, l, T, B, h, w, s);
+            m->dir_mask = 2;
+            if (st == BDE_OK) st = run_recurrent_steps_sbk(m, l, T, B, h, w, s2);
+            m->dir_mask = 3;
+            BDE_HIP(hipEventRecord(m->dir_join[slot], s2));
+            BDE_HIP(hipStreamWaitEvent(s, m->dir_join[slot], 0));
+            return st;
+        }
+        return run_recurrent_steps_sbk(m, l, T, B, h, w, s);
+    }
     if (!(m->debug_skip & 4) && ws.hsb[l] != nullptr) {
         BDE_REQUIRE(m->dir_mask == 3, "the split-bf16 recurrent step (lstm_sb) runs both directions only");
         return run_recurrent_steps_sb(m, l, T, B, h, w, s);
@@ -2372,6 +2401,11 @@ void bde_destroy(bde_model* m) {
         // (pstream[i] belongs to the per-device pool, pipeline_stream())
     }
     if (m->dev) (void)hipFree(m->dev);
+    for (int i = 0; i < 4; ++i) {
+        if (m->dir_fork[i]) (void)hipEventDestroy(m->dir_fork[i]);
+        if (m->dir_join[i]) (void)hipEventDestroy(m->dir_join[i]);
+        if (m->dir_stream[i]) (void)hipStreamDestroy(m->dir_stream[i]);
+    }
     for (auto& sp : m->prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : m->prof_pool) (void)hipEventDestroy(e);
     for (auto e : m->frame_ev) (void)hipEventDestroy(e);
@@ -2610,6 +2644,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_two_streams") { m->lstm_two_streams = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_sbk") {
         if (m->use_lstm_sbk != (int)value)
             for (auto& w : m->wslots) w.release();
