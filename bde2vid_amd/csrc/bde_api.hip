@@ -1484,6 +1484,7 @@ static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int
         a.B = B; a.Ch = C; a.H = h; a.W = w;
         a.first = st == 0;
         a.stamps = (st == T / 2) ? m->tok_stamps : nullptr;                // diagnostics (bde_debug_token_stamps): one mid-sweep step
+        a.stamp_mode = m->tok_debug == 9 ? 1 : 0;
         if (one_dir) {                                                     // group 0 of a one-group launch = the chosen direction
             a.hin += dsel * a.hin_gs; a.hsb += dsel * a.hin_gs;
             a.wpk += dsel * a.w_gs;
@@ -2711,10 +2712,13 @@ int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n) {
     if (!m->tok_stamps) {
         BDE_HIP(hipMalloc((void**)&m->tok_stamps, sizeof(unsigned long long) * 64 * 4 * 8));
         BDE_HIP(hipMemset(m->tok_stamps, 0, sizeof(unsigned long long) * 64 * 4 * 8));
+        BDE_HIP(hipMemset(m->tok_stamps + 2046, 0xff, sizeof(unsigned long long)));     // (slot 2046: an atomicMin target, lstm_sb.h)
     }
     if (host_out) {
         BDE_HIP(hipDeviceSynchronize());
         BDE_HIP(hipMemcpy(host_out, m->tok_stamps, sizeof(int64_t) * std::min(n, 64 * 4 * 8), hipMemcpyDeviceToHost));
+        BDE_HIP(hipMemset(m->tok_stamps + 2046, 0xff, sizeof(unsigned long long)));
+        BDE_HIP(hipMemset(m->tok_stamps + 2047, 0, sizeof(unsigned long long)));
     }
     return BDE_OK;
 }

@@ -48,14 +48,17 @@ struct LstmSbArgs {
     int first;                      // 1: h_prev = c_prev = 0, no contraction
     int TR, TC, tiles_x;            // a workgroup's pixels: TR image rows x TC columns (TR * TC <= NT * 32), tiles per row
     unsigned long long* stamps;     // diagnostics only: s_memtime per phase, [block < 64][wave < 4][8]
+    int stamp_mode;                 // 1: instead, s_memrealtime start / end of every workgroup < 1000 ([wg][2])
 };
 #define LSB_STAMP(i)                                                                              \
     do {                                                                                          \
-        if (a.stamps && lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)       \
+        if (a.stamps && !a.stamp_mode && lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)       \
             a.stamps[(blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime();           \
     } while (0)
 
-template <int RTW, int KW, int NT, int MAXI>
+// DB: two sets of halo tiles; stage s + 1 is requested before the MFMAs of stage s (where three workgroups' worth of LDS allows:
+// the workgroups of a launch run in lockstep, so their halo waits coincide and nobody covers them).
+template <int RTW, int KW, int NT, int MAXI, bool DB>
 __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a) {
     static_assert(RTW * KW == 4, "four waves per workgroup");
     constexpr int QW = 4 / KW;                          // register groups (= hidden channels x 2) a wave finishes per tile
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     const int tc = min(a.TC, a.W - x0), tr = min(a.TR, a.H - y0);   // live extent of this tile
     const int IW = a.TC + 2, IR = a.TR + 2;
     LSB_STAMP(0);
+    const unsigned long long real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostics: 100 MHz reference clock)
 
     // this lane's pixel of each 32-pixel tile: q = t * 32 + (lane & 31) -> (row q / TC, column q % TC)
     const float inv_tc = 1.0f / (float)a.TC;
@@ -154,7 +158,9 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
             pmask |= (unsigned long long)(part & 3) << (2 * it);
         }
         const unsigned char* zero16 = reinterpret_cast<const unsigned char*>(a.zeros);
+        const int set_bytes = KW * tile_bytes;            // one set of halo tiles (all parts of K)
         auto stage = [&](int s) {
+            unsigned char* dst = lsb + (DB ? (s & 1) * set_bytes : 0);
 #pragma unroll
             for (int it = 0; it < MAXI; ++it) {
                 const int blk = wave + it * 4;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                     const int part = (int)((pmask >> (2 * it)) & 3ull);
                     const unsigned char* src = ((vmask >> it) & 1u) ? inb + (long)(part * stages + s) * plane + goff[it] : zero16;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(lsb + blk * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
                 }
             }
         };
@@ -176,14 +182,18 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         for (int q = 0; q < PF; ++q)
 #pragma unroll
             for (int k = 0; k < 3; ++k) af[q][k] = wfr[((long)min(q, S - 1) * 3 + k) * 64];
-        const unsigned char* tile = lsb + kp * tile_bytes;
         LSB_STAMP(1);
+        if (DB) stage(0);
         for (int s = 0; s < stages; ++s) {
-            __syncthreads();                             // every wave is done with the previous stage's tiles
-            stage(s);
+            if (!DB) {
+                __syncthreads();                         // every wave is done with the previous stage's tiles
+                stage(s);
+            }
             if (s == stages - 1) epi_load();             // the tail's operands travel during the last stage
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __syncthreads();                             // stage s has landed for every wave (and, DB: stage s - 1's tiles are free)
+            if (DB && s + 1 < stages) stage(s + 1);
+            const unsigned char* tile = lsb + (DB ? (s & 1) * set_bytes : 0) + kp * tile_bytes;
             if (s == 0) LSB_STAMP(2);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
@@ -297,10 +307,20 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         }
     }
     LSB_STAMP(6);
+    if (a.stamps && !a.stamp_mode && lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)
+        a.stamps[(blockIdx.x * 4 + wave) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - real0;
+    if (a.stamps && a.stamp_mode && lane == 0 && wave == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin < 1000) { a.stamps[2 * lin] = real0; a.stamps[2 * lin + 1] = __builtin_amdgcn_s_memrealtime(); }
+    }
+    if (a.stamps && !a.stamp_mode && lane == 0 && wave == 0) {            // diagnostics: first start / last end over ALL workgroups (100 MHz ticks)
+        atomicMin(a.stamps + 2046, real0);
+        atomicMax(a.stamps + 2047, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
-struct LstmSbShape { int rtw, kw, nt, TR, TC, tiles_x, tiles_y, maxi; size_t lds; bool ok; };
+struct LstmSbShape { int rtw, kw, nt, TR, TC, tiles_x, tiles_y, maxi; size_t lds; bool ok, db; };
 
 // How a level's step is cut (see the header): KW parts of K per workgroup by the number of 16-channel chunks, NT by the map width.
 static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw) {
@@ -323,7 +343,8 @@ static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw) {
     const size_t stage_b = (size_t)blocks * 1024;
     const size_t red_b = s.kw > 1 ? (size_t)4 * s.nt * 16 * 64 * 4 : 0;
     const size_t hst_b = (size_t)s.rtw * s.nt * 32 * 3 * 16;
-    s.lds = std::max(stage_b, std::max(red_b, hst_b));
+    s.db = 2 * stage_b * 3 <= 150 * 1024;                 // double-buffered halo while three workgroups still fit a CU
+    s.lds = std::max((s.db ? 2 : 1) * stage_b, std::max(red_b, hst_b));
     s.ok = s.maxi <= 24 && s.lds <= 80 * 1024;            // (two workgroups per CU at least)
     return s;
 }
@@ -342,9 +363,9 @@ static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
 }
 
 #ifdef BDE_CONV_TU
-template <int RTW, int KW, int NT, int MAXI>
+template <int RTW, int KW, int NT, int MAXI, bool DB>
 static int lstm_sb_launch_t(const LstmSbArgs& a, const LstmSbShape& s, int G, hipStream_t stream) {
-    auto kern = lstm_sb_step_kernel<RTW, KW, NT, MAXI>;
+    auto kern = lstm_sb_step_kernel<RTW, KW, NT, MAXI, DB>;
     static unsigned char raised[BDE_MAX_DEVICES];
     if (s.lds > 64 * 1024) BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
     dim3 grid(s.tiles_x * s.tiles_y, cdiv(a.Ch / 8, RTW), G * a.B);
@@ -354,9 +375,14 @@ static int lstm_sb_launch_t(const LstmSbArgs& a, const LstmSbShape& s, int G, hi
 }
 template <int RTW, int KW, int NT>
 static int lstm_sb_launch_m(const LstmSbArgs& a, const LstmSbShape& s, int G, hipStream_t stream) {
-    if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6>(a, s, G, stream);
-    if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12>(a, s, G, stream);
-    return lstm_sb_launch_t<RTW, KW, NT, 24>(a, s, G, stream);
+    if (s.db) {
+        if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6, true>(a, s, G, stream);
+        if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12, true>(a, s, G, stream);
+        return lstm_sb_launch_t<RTW, KW, NT, 24, true>(a, s, G, stream);
+    }
+    if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6, false>(a, s, G, stream);
+    if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12, false>(a, s, G, stream);
+    return lstm_sb_launch_t<RTW, KW, NT, 24, false>(a, s, G, stream);
 }
 int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream) {
     const LstmSbShape s = lstm_sb_shape(a.Ch, a.H, a.W);

@@ -39,7 +39,24 @@ for l in range(3):
     torch.cuda.synchronize()
     out = (C.c_int64 * 2048)()
     L.bde_debug_token_stamps(m._h, out, 2048)
+    print(f'level {l}: first workgroup start -> last workgroup end: {(out[2047] - out[2046]) / 100.0:.1f} us (all workgroups, s_memrealtime)')
     a = np.array(out[:], dtype=np.int64).reshape(64, 4, 8)
     d = a[:, :, 1:7] - a[:, :, 0:6]
     print(f'level {l} phase cycles (prologue, first DMA, stages, barrier, reduce, tail+store) median:', np.median(d.reshape(-1, 6), axis=0),
-          ' total', np.median(a[:, :, 6] - a[:, :, 0]), ' spread of start', int(a[:, :, 0].max() - a[:, :, 0].min()), ' end', int(a[:, :, 6].max() - a[:, :, 6].min()))
+          ' total', np.median(a[:, :, 6] - a[:, :, 0]), ' in-kernel clock GHz', round(float(np.median((a[:, :, 6] - a[:, :, 0]) / np.maximum(a[:, :, 7], 1))) * 0.1, 3), ' spread of start', int(a[:, :, 0].max() - a[:, :, 0].min()), ' end', int(a[:, :, 6].max() - a[:, :, 6].min()))
+
+m.set_tuning('tok_debug', 9)
+for l in range(3):
+    x = torch.randn(T, 1, cfg.enc_in(l), H >> l, W >> l, device='cuda', generator=g)
+    ops.recurrent_conv(m, l, 0, x)
+    torch.cuda.synchronize()
+    out = (C.c_int64 * 2048)()
+    L.bde_debug_token_stamps(m._h, out, 2048)
+    nwg = {0: 692, 1: 704, 2: 512}[l] if (H, W) == (184, 240) else 1000
+    a = np.array(out[:2000], dtype=np.int64).reshape(1000, 2)[:nwg]
+    a = a[a[:, 1] > 0]
+    t0 = a[:, 0].min()
+    st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
+    print(f'level {l}: {len(a)} workgroups; start us: min {st.min():.1f} median {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f}; '
+          f'duration us: median {np.median(en - st):.1f} max {(en - st).max():.1f}; end max {en.max():.1f}; started after 5 us: {(st > 5).sum()}')
+m.set_tuning('tok_debug', 0)
