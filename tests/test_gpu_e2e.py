@@ -513,3 +513,31 @@ def test_one_sequence_split_over_two_ranks_by_direction(tmp_path):
         assert v['equal'], f'{name}: split frames differ from the single-GPU forward'
         assert v['repeat'], f'{name}: second split call differs'
         assert v['err'] <= TOL, (name, v['err'])
+
+
+def test_round3_kernels_agree_with_the_kernels_they_replace():
+    """The split-bf16 recurrent step (lstm_sb.h), the split-bf16 GEMM phases of the attention block (winblock_sb.h), the q|k|v
+    fusion of the level-2 core (wideblock.h) and the two-stream sweep option: each switched off in turn must give the frames of
+    the default build to fp32 rounding (canonical config, 184x240, T = 6) -- and all of them match the reference's golden frames
+    through the other tests."""
+    from tests.util import golden_inputs
+    from bde2vid_amd import canonical
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.weights import formula_state_dict
+    cfg = canonical()
+    m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
+    xs = golden_inputs(6, 1, 5, 184, 240, 2468)
+    inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    with torch.no_grad():
+        base = torch.stack(m(inp)).clone()
+        assert [m.get_info(f'sb_lstm{l}') for l in range(3)] == [1, 1, 1]
+        for key, off, on in (('lstm_sbk', 0, 1), ('winblock_sb', 0, 1), ('wide_fuse_qkv', 0, 1), ('lstm_two_streams', 1, 0)):
+            m.set_tuning(key, off)
+            try:
+                y = torch.stack(m(inp))
+                y2 = torch.stack(m(inp))                       # second call: the captured graph of the switched schedule
+            finally:
+                m.set_tuning(key, on)
+            assert maxabs(y, base) <= 2e-5, key
+            assert torch.equal(y, y2), key
+        assert torch.equal(torch.stack(m(inp)), base)
