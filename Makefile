@@ -1,15 +1,15 @@
-# Builds the gfx950 shared library.  hipcc cross-compiles without a GPU.  Two translation units (the conv-shaped
-# kernels and everything else) compile in parallel: `make -j2`.
+# Builds the gfx950 shared library.  hipcc cross-compiles without a GPU.  Three translation units (the fp32 conv-shaped
+# kernels, the split-operand kernels and everything else) compile in parallel: `make -j3`.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 LIB    = bde2vid_amd/libbde2vid.so
-SRCS   = bde2vid_amd/csrc/bde_api.hip bde2vid_amd/csrc/conv_tu.hip
+SRCS   = bde2vid_amd/csrc/bde_api.hip bde2vid_amd/csrc/conv_tu.hip bde2vid_amd/csrc/sb_tu.hip
 OBJS   = $(SRCS:bde2vid_amd/csrc/%.hip=build/%.o)
 HDR    = $(wildcard bde2vid_amd/csrc/*.h) include/bde2vid.h
 FLAGS  = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -fvisibility=hidden -DBDE_BUILD
 
 all:
-	@$(MAKE) --no-print-directory -j2 $(LIB)
+	@$(MAKE) --no-print-directory -j3 $(LIB)
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)

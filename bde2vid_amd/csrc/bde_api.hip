@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
 // planes: [N][C/16][2Hs][2Ws][3 terms][16 channels] bf16.  grid (ceil(4 Hs Ws / 128), C/16 chunks, N), thread = (output
 // pixel, half of the chunk): 2 x 2 source pixels of 8 channels of both tensors, three 16-byte stores.  Same expression and
 // weights per output as upsample2x_sum_kernel.
+template <int TERMS>
 __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                    unsigned short* __restrict__ out, int C, int Hs, int Ws) {
     const int Wo = 2 * Ws;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* 
     if (xa == xb) wxb = 1.f;
     const float wya = 1.f - wyb, wxa = 1.f - wxb;
     const int iaa = ya * Ws + xa, iab = ya * Ws + xb, iba = yb * Ws + xa, ibb = yb * Ws + xb;
-    unsigned short t[3][8];
+    unsigned short t[8][TERMS];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = c16 * 16 + half * 8 + q;
@@ -211,22 +212,23 @@ __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* 
             }
             o = wya * (wxa * vaa + wxb * vab) + wyb * (wxa * vba + wxb * vbb);
         }
-        sb_split3(o, t[0][q], t[1][q], t[2][q]);
+        sb_split_dev<TERMS>(o, t[q]);
     }
-    unsigned short* d = out + (((n * C16 + c16) * HWo + p) * 3) * 16 + half * 8;
+    unsigned short* d = out + (((n * C16 + c16) * HWo + p) * TERMS) * 16 + half * 8;
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
+    for (int kk = 0; kk < TERMS; ++kk) {
         uint4 v;
-        v.x = t[kk][0] | ((unsigned)t[kk][1] << 16);
-        v.y = t[kk][2] | ((unsigned)t[kk][3] << 16);
-        v.z = t[kk][4] | ((unsigned)t[kk][5] << 16);
-        v.w = t[kk][6] | ((unsigned)t[kk][7] << 16);
+        v.x = t[0][kk] | ((unsigned)t[1][kk] << 16);
+        v.y = t[2][kk] | ((unsigned)t[3][kk] << 16);
+        v.z = t[4][kk] | ((unsigned)t[5][kk] << 16);
+        v.w = t[6][kk] | ((unsigned)t[7][kk] << 16);
         *reinterpret_cast<uint4*>(d + kk * 16) = v;
     }
 }
-static int upsample2x_sum_split(const float* a, const float* b, void* out_sb, int N, int C, int Hs, int Ws, hipStream_t s) {
-    hipLaunchKernelGGL(upsample2x_sum_split_kernel, dim3((unsigned)cdivl(4L * Hs * Ws, 128), cdiv(C, 16), (unsigned)N), dim3(256), 0, s,
-                       a, b, (unsigned short*)out_sb, C, Hs, Ws);
+static int upsample2x_sum_split(const float* a, const float* b, void* out_sb, int N, int C, int Hs, int Ws, int terms, hipStream_t s) {
+    const dim3 grid((unsigned)cdivl(4L * Hs * Ws, 128), cdiv(C, 16), (unsigned)N);
+    if (terms == 2) hipLaunchKernelGGL(upsample2x_sum_split_kernel<2>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws);
+    else hipLaunchKernelGGL(upsample2x_sum_split_kernel<3>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
@@ -321,7 +323,11 @@ struct PackedLayer {
     long w_off = -1, b_off = -1, s_off = -1;   // weights / bias / lnsum
     long w_sz = 0;                              // floats of one group's packed weights
     int G = 1;                                  // groups packed back to back (fwd, bwd)
-    long sb_off = -1, sb_sz = 0;                // split-bf16 packing (conv_sb.h), floats; one group = sb_sz
+    long sb_off = -1, sb_sz = 0;                // split packing, three bf16 terms (conv_sb.h), floats; one group = sb_sz
+    long sh_off = -1, sh_sz = 0;                // split packing, two fp16 terms, weights times 1 / sh_unscale (split.h)
+    long sh_unscale_off = -1;                   // ... and the inverse scale, one float in the packed image (a receiver of the image has no weights)
+    long split_off(int terms) const { return terms == 2 ? sh_off : sb_off; }
+    long split_sz(int terms) const { return terms == 2 ? sh_sz : sb_sz; }
     int sb_chunks = 0;                          // 16-channel chunks
     mutable int sb_used = 0;                    // the latest launch of this layer ran on conv_sb_kernel (bde_get_info "sb_*")
     int G_decide = 0;                           // a one-group view of a grouped layer: choose launch shapes as for this many groups
@@ -336,6 +342,7 @@ static PackedLayer group_view(const PackedLayer& pl, int g) {
     if (v.b_off >= 0) v.b_off += (long)g * pl.Cout;
     if (v.s_off >= 0) v.s_off += (long)g * pl.Cout;
     if (v.sb_off >= 0) v.sb_off += g * pl.sb_sz;
+    if (v.sh_off >= 0) v.sh_off += g * pl.sh_sz;
     return v;
 }
 
@@ -400,21 +407,39 @@ static long pack16x4(Arena& ar, const float* w, int rows, int K) {
     return off;
 }
 
-// winblock_sb.h: rows x K as three bf16 terms in A-fragment order of v_mfma_f32_16x16x32_bf16:
+// w * scale as `terms` 16-bit terms (split.h)
+static inline void split_terms(float w, int terms, float scale, unsigned short (&t)[3]) {
+    if (terms == 2) { sb_split2(w * scale, t[0], t[1]); t[2] = 0; }
+    else sb_split3(w, t[0], t[1], t[2]);
+}
+// the power-of-two packing scale of a group of layers in the two-term format (1 for three terms)
+static float split_scale(const std::vector<const DenseLayer*>& groups, int terms) {
+    if (terms != 2) return 1.f;
+    float sc = 0.f;
+    for (const DenseLayer* d : groups) {
+        const float v = sb_weight_scale(d->w.data(), (long)d->w.size());
+        sc = sc == 0.f ? v : std::min(sc, v);
+    }
+    return sc > 0.f ? sc : 1.f;
+}
+
+// winblock_sb.h: rows x K as split terms in A-fragment order of v_mfma_f32_16x16x32_{bf16,f16}:
 // [row tile 16][k-step 32][term][64 lanes][8]: lane l = W[16 tile + (l & 15)][32 kstep + 8 (l >> 4) + j]; K % 32 == 0.
-static long pack16_split(Arena& ar, const float* w, int rows, int K) {
+static long pack16_split(Arena& ar, const float* w, int rows, int K, int terms, long unscale_off) {
     const int nrt = cdiv(rows, 16), nks = K / 32;
-    const long n_u16 = (long)nrt * nks * 3 * 64 * 8;
+    const long n_u16 = (long)nrt * nks * terms * 64 * 8;
     const long off = ar.alloc(n_u16 / 2);
     unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + off);
+    const float scale = terms == 2 ? sb_weight_scale(w, (long)rows * K) : 1.f;
+    if (unscale_off >= 0) ar.host[unscale_off] = 1.f / scale;
     for (int rt = 0; rt < nrt; ++rt)
         for (int ks = 0; ks < nks; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
                     const int r = rt * 16 + (l & 15), k = ks * 32 + 8 * (l >> 4) + j;
                     unsigned short t3[3];
-                    sb_split3(r < rows ? w[(long)r * K + k] : 0.f, t3[0], t3[1], t3[2]);
-                    for (int t = 0; t < 3; ++t) dst[((((long)rt * nks + ks) * 3 + t) * 64 + l) * 8 + j] = t3[t];
+                    split_terms(r < rows ? w[(long)r * K + k] : 0.f, terms, scale, t3);
+                    for (int t = 0; t < terms; ++t) dst[((((long)rt * nks + ks) * terms + t) * 64 + l) * 8 + j] = t3[t];
                 }
     return off;
 }
@@ -490,19 +515,22 @@ static PackedLayer pack_lstm8(Arena& ar, const std::vector<const DenseLayer*>& g
     return pl;
 }
 
-// lstm_sb.h: h-part of the gates as three bf16 terms, rows GATE-INTERLEAVED (row 8 q + 4 hl + gate of tile rt = that gate of hidden
-// channel 8 rt + 4 hl + q), A-fragment order of v_mfma_f32_32x32x16_bf16: [group][row tile][chunk 16][tap][term][64 lanes][8]
-static void pack_lstm_sbk(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
+// lstm_sb.h: h-part of the gates as split terms, rows GATE-INTERLEAVED (row 8 q + 4 hl + gate of tile rt = that gate of hidden
+// channel 8 rt + 4 hl + q), A-fragment order of the 32x32x16 MFMA: [group][row tile][chunk 16][tap][term][64 lanes][8]
+static void pack_lstm_sbk_terms(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups, int terms) {
     const DenseLayer& d0 = *groups[0];
     const int Ch = d0.rows / 4, nrt = cdiv(Ch, 8), C16 = cdiv(d0.Cin, 16);
-    const long per_group_u16 = (long)nrt * C16 * 9 * 3 * 64 * 8;
+    const long per_group_u16 = (long)nrt * C16 * 9 * terms * 64 * 8;
     pl.Cin = d0.Cin; pl.Cout = d0.rows; pl.KS = 3; pl.G = (int)groups.size();
-    pl.sb_sz = per_group_u16 / 2;
+    const long sz = per_group_u16 / 2;
+    const long off = ar.alloc(sz * (long)groups.size());
+    const float scale = split_scale(groups, terms);
     pl.sb_chunks = C16;
-    pl.sb_off = ar.alloc(pl.sb_sz * (long)groups.size());
+    if (terms == 2) { pl.sh_off = off; pl.sh_sz = sz; pl.sh_unscale_off = ar.alloc(4); ar.host[pl.sh_unscale_off] = 1.f / scale; }
+    else { pl.sb_off = off; pl.sb_sz = sz; }
     for (size_t g = 0; g < groups.size(); ++g) {
         const DenseLayer& d = *groups[g];
-        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + pl.sb_off + (long)g * pl.sb_sz);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + off + (long)g * sz);
         for (int rt = 0; rt < nrt; ++rt)
             for (int ch = 0; ch < C16; ++ch)
                 for (int tap = 0; tap < 9; ++tap)
@@ -512,25 +540,32 @@ static void pack_lstm_sbk(Arena& ar, PackedLayer& pl, const std::vector<const De
                             const int rho = l & 31, hc = rt * 8 + 4 * ((rho >> 2) & 1) + (rho >> 3), gate = rho & 3, ci = ch * 16 + 8 * (l >> 5) + j;
                             const float w = (hc < Ch && ci < d.Cin) ? d.w[((long)(gate * Ch + hc) * d.Cin + ci) * 9 + tap] : 0.f;
                             unsigned short t3[3];
-                            sb_split3(w, t3[0], t3[1], t3[2]);
-                            for (int k = 0; k < 3; ++k)
-                                dst[(((((long)rt * C16 + ch) * 9 + tap) * 3 + k) * 64 + l) * 8 + j] = t3[k];
+                            split_terms(w, terms, scale, t3);
+                            for (int k = 0; k < terms; ++k)
+                                dst[(((((long)rt * C16 + ch) * 9 + tap) * terms + k) * 64 + l) * 8 + j] = t3[k];
                         }
     }
 }
+static void pack_lstm_sbk(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
+    pack_lstm_sbk_terms(ar, pl, groups, 3);
+    pack_lstm_sbk_terms(ar, pl, groups, 2);
+}
 
-// conv_sb.h: the weights as three bf16 terms in A-fragment order of v_mfma_f32_32x32x16_bf16:
+// conv_sb.h: the weights as split terms in A-fragment order of the 32x32x16 MFMA:
 // [group][co tile 32][chunk 16][tap][term][64 lanes][8]: lane l = W[32 tile + (l & 31)][16 chunk + 8 (l >> 5) + j][tap]
-static void pack_split_bf16(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
+static void pack_split_terms(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups, int terms) {
     const DenseLayer& d0 = *groups[0];
     const int taps = d0.KS * d0.KS, ncot = cdiv(d0.rows, 32), C16 = cdiv(d0.Cin, 16);
-    const long per_group_u16 = (long)ncot * C16 * taps * 3 * 64 * 8;
-    pl.sb_sz = per_group_u16 / 2;                                   // in floats
+    const long per_group_u16 = (long)ncot * C16 * taps * terms * 64 * 8;
+    const long sz = per_group_u16 / 2;                              // in floats
+    const long off = ar.alloc(sz * (long)groups.size());
+    const float scale = split_scale(groups, terms);
     pl.sb_chunks = C16;
-    pl.sb_off = ar.alloc(pl.sb_sz * (long)groups.size());
+    if (terms == 2) { pl.sh_off = off; pl.sh_sz = sz; pl.sh_unscale_off = ar.alloc(4); ar.host[pl.sh_unscale_off] = 1.f / scale; }
+    else { pl.sb_off = off; pl.sb_sz = sz; }
     for (size_t g = 0; g < groups.size(); ++g) {
         const DenseLayer& d = *groups[g];
-        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + pl.sb_off + (long)g * pl.sb_sz);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + off + (long)g * sz);
         for (int ct = 0; ct < ncot; ++ct)
             for (int ch = 0; ch < C16; ++ch)
                 for (int tap = 0; tap < taps; ++tap)
@@ -539,11 +574,15 @@ static void pack_split_bf16(Arena& ar, PackedLayer& pl, const std::vector<const 
                             const int row = ct * 32 + (l & 31), ci = ch * 16 + 8 * (l >> 5) + j;
                             const float w = (row < d.rows && ci < d.Cin) ? d.w[((long)row * d.Cin + ci) * taps + tap] : 0.f;
                             unsigned short t3[3];
-                            sb_split3(w, t3[0], t3[1], t3[2]);
-                            for (int k = 0; k < 3; ++k)
-                                dst[(((((long)ct * C16 + ch) * taps + tap) * 3 + k) * 64 + l) * 8 + j] = t3[k];
+                            split_terms(w, terms, scale, t3);
+                            for (int k = 0; k < terms; ++k)
+                                dst[(((((long)ct * C16 + ch) * taps + tap) * terms + k) * 64 + l) * 8 + j] = t3[k];
                         }
     }
+}
+static void pack_split_bf16(Arena& ar, PackedLayer& pl, const std::vector<const DenseLayer*>& groups) {
+    pack_split_terms(ar, pl, groups, 3);
+    pack_split_terms(ar, pl, groups, 2);
 }
 
 // Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
@@ -593,7 +632,9 @@ struct AttnBlock {
     PackedLayer qkv, proj, fc1, fc2;
     long proj16 = -1, fc1_16 = -1, fc2_16 = -1, qkv16 = -1;   // 16x16x4 packings for token_fused.h
     long projW = -1, fc1W = -1, fc2W = -1, qkvW = -1;         // four-k-steps-per-load packings for wideblock.h
-    long projS = -1, fc1S = -1, fc2S = -1, qkvS = -1;         // split-bf16 packings for winblock_sb.h
+    long projS = -1, fc1S = -1, fc2S = -1, qkvS = -1;         // split packings for winblock_sb.h, three bf16 terms
+    long projH = -1, fc1H = -1, fc2H = -1, qkvH = -1;         // two fp16 terms; unscaleH -> {q|k|v, proj, fc1, fc2} inverse scales
+    long unscaleH = -1;                                       // (four floats in the packed image)
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -694,7 +735,9 @@ struct bde_model {
     int wide_fuse_qkv = 1;        // ... with the query frame's q | k | v computed inside the attention core (no GEMM launch of its own)
     int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
     int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
-    int conv_sb = 1;              // batched convolutions on the bf16 matrix cores with three-term split operands (conv_sb.h)
+    int conv_sb = 1;              // batched convolutions on the 16-bit matrix cores with split operands (conv_sb.h)
+    int sb_terms = BDE_DEFAULT_SB_TERMS;   // format of every split operand (split.h): 2 = two fp16 terms (three MFMAs per fp32 block;
+                                  // activations must stay below 65520), 3 = three bf16 terms (six MFMAs; fp32's exponent range)
     int lstm_two_streams = 0;     // the two sweep directions of a level as two launch chains on two streams (independent until the merge);
                                   // measured: 1208 vs 1444 frames/s pipelined, 1135 vs 1161 single stream -- half-size launches take almost as long: off
     hipStream_t dir_stream[4] = {};         // per workspace slot: the second direction's stream and its fork / join events
@@ -859,6 +902,7 @@ static int build_packed(bde_model* m) {
         DenseLayer d;
         BDE_TRY(dense_convlayer(m, "head.", bc, c.num_bins, ks, &d));
         m->head = pack_layer(ar, {&d}, false);
+        pack_split_bf16(ar, m->head, {&d});
     }
     const char* dirs[2] = {"forward_encoder", "backward_encoder"};
     for (int l = 0; l < L; ++l) {
@@ -1051,10 +1095,15 @@ static int build_packed(bde_model* m) {
                 ab.qkvW = pack16x4(ar, qkv.w.data(), 3 * C, C);
             }
             if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
-                ab.projS = pack16_split(ar, proj.w.data(), C, C);
-                ab.fc1S = pack16_split(ar, fc1.w.data(), hid, C);
-                ab.fc2S = pack16_split(ar, fc2.w.data(), C, hid);
-                ab.qkvS = pack16_split(ar, qkv.w.data(), 3 * C, C);
+                ab.projS = pack16_split(ar, proj.w.data(), C, C, 3, -1);
+                ab.fc1S = pack16_split(ar, fc1.w.data(), hid, C, 3, -1);
+                ab.fc2S = pack16_split(ar, fc2.w.data(), C, hid, 3, -1);
+                ab.qkvS = pack16_split(ar, qkv.w.data(), 3 * C, C, 3, -1);
+                ab.unscaleH = ar.alloc(4);
+                ab.qkvH = pack16_split(ar, qkv.w.data(), 3 * C, C, 2, ab.unscaleH);
+                ab.projH = pack16_split(ar, proj.w.data(), C, C, 2, ab.unscaleH + 1);
+                ab.fc1H = pack16_split(ar, fc1.w.data(), hid, C, 2, ab.unscaleH + 2);
+                ab.fc2H = pack16_split(ar, fc2.w.data(), C, hid, 2, ab.unscaleH + 3);
             }
             if (C % 16 == 0 && token_lds_bytes(C) <= 150 * 1024) {
                 ab.proj16 = pack16(ar, proj.w.data(), C, C);
@@ -1137,7 +1186,7 @@ struct ConvCall {
 static bool conv_takes_sb(const bde_model* m, const PackedLayer& pl, int stride, int N, int Hs, int Ws) {
     const int pad = pl.KS / 2;
     const int Ho = (Hs + 2 * pad - pl.KS) / stride + 1, Wo = (Ws + 2 * pad - pl.KS) / stride + 1;
-    return m->conv_sb && pl.sb_off >= 0 && conv_sb_fits(pl.KS, stride, pl.Cout, Ws, Ho, Wo) &&
+    return m->conv_sb && pl.split_off(m->sb_terms) >= 0 && conv_sb_fits(pl.KS, stride, pl.Cout, Ws, Ho, Wo, m->sb_terms) &&
            (long)(pl.G_decide ? pl.G_decide : pl.G) * N * Ho * Wo >= 16384;
 }
 
@@ -1179,9 +1228,10 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     a.decide_groups = pl.G_decide;
     if (cc.out_sb) {
         a.sb_out = reinterpret_cast<unsigned short*>(cc.out_sb);
-        a.sb_out_ns = (long)cdiv(pl.Cout, 16) * a.Ho * a.Wo * 48;
+        a.sb_out_ns = (long)cdiv(pl.Cout, 16) * a.Ho * a.Wo * (16 * m->sb_terms);
         a.sb_out_gs = cc.out_sb_gs * 2;
     }
+    a.sb_terms = m->sb_terms;
     if (cc.pred_out) {
         a.pred_w = m->P(m->predw_off);
         a.pred_b = m->P(m->predb_off);
@@ -1193,7 +1243,8 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     // (measured at the canonical sizes, us: 3x3 gate convs 530 / 497 / 505 against 954 / 954 / 989 on the fp32 matrix path;
     //  5x5: decoder 0 488 vs 633, decoder 1 (64 channels) 502 vs 641, encoder 1 / 2 (stride 2) 271 / 300 vs 345 / 335;
     //  conv_sb_pick has no shape for 32 output channels or for the stride-2 halo of level 0, those stay on the fp32 kernels)
-    if (cc.in_sb || (!cc.pred_out && conv_takes_sb(m, pl, cc.stride, cc.N, cc.Hs, cc.Ws))) {
+    // (the fused predI epilogue needs every output channel of a pixel in one wave: 32 channels)
+    if (cc.in_sb || ((!cc.pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, cc.stride, cc.N, cc.Hs, cc.Ws))) {
         // split the input into three bf16 terms (SB16) unless its producer already wrote it that way, then the convolution
         // on the bf16 matrix cores; the small launches (a few frames of a small map) stay on the fp32 kernels
         Workspace& ws = const_cast<bde_model*>(m)->W();
@@ -1201,14 +1252,15 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         const long frames = (grouped_in ? pl.G : 1) * (long)cc.N;
         const long need = split_bf16_bytes(frames, pl.Cin, (long)cc.Hs * cc.Ws);
         if (cc.in_sb || (ws.sb && need <= ws.sb_bytes)) {
-            if (!cc.in_sb) BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, s));
+            if (!cc.in_sb) BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, m->sb_terms, s));
             ConvArgs b = a;
             b.in = cc.in_sb ? cc.in : ws.sb;
-            b.wpk = m->P(pl.sb_off);
-            b.w_gs = pl.sb_sz;
+            b.wpk = m->P(pl.split_off(m->sb_terms));
+            b.w_gs = pl.split_sz(m->sb_terms);
+            b.acc_scale = m->P(pl.sh_unscale_off);
             b.nchunks = pl.sb_chunks;
             b.zeros = m->P(m->zero_off);
-            b.in_ns = (long)pl.sb_chunks * cc.Hs * cc.Ws * SB_PIX_BYTES / 4;
+            b.in_ns = (long)pl.sb_chunks * cc.Hs * cc.Ws * sb_pix_bytes(m->sb_terms) / 4;
             b.in_gs = cc.in_sb ? cc.in_gs : (grouped_in ? b.in_ns * cc.N : 0);
             bool launched = false;
             BDE_TRY(conv_sb_launch(pl.KS, cc.stride, b, pl.G, s, &launched));
@@ -1397,7 +1449,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     if (one_dir) e.out += dsel * e.out_gs;
     // the gate convolution reads its input as SB16 (conv_sb.h): the encoder conv's epilogue then writes that image directly
     // (6 B per element) and the fp32 planes + their conversion pass are skipped
-    const long sb_fs = (long)cdiv(C, 16) * hw * SB_PIX_BYTES / 4;         // floats of one SB16 frame
+    const long sb_fs = (long)cdiv(C, 16) * hw * sb_pix_bytes(m->sb_terms) / 4;   // floats of one SB16 frame
     const bool fuse = m->fuse_enc_sb && C % 32 == 0 && conv_takes_sb(m, gx_v, 1, nf, h, w) &&
                       ws.sb2 && split_bf16_bytes(2 * TB, C, hw) <= ws.sb2_bytes;
     if (fuse) {
@@ -1435,7 +1487,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
 static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w) {
     if (m->lstm_sb_mode == 0 || !m->conv_sb) return false;
     const int C = m->cout(l);
-    if (m->lstm_sb_off(l) < 0 || !conv_sb_fits(3, 1, 4 * C, w, h, w)) return false;
+    if (m->lstm_sb_off(l) < 0 || !conv_sb_fits(3, 1, 4 * C, w, h, w, m->sb_terms)) return false;
     if (m->lstm_sb_mode == 1) return true;
     const long wgs = cdivl((long)h * w, 128) * cdivl(4 * C, 128) * 2 * B;
     return wgs >= 160 && cdiv(C, 16) <= 8;
@@ -1445,7 +1497,7 @@ static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w) {
 static bool lstm_sbk_ok(const bde_model* m, int l, int h, int w) {
     if (!m->use_lstm_sbk || m->lstm_sb_mode != 0 || !m->conv_sb) return false;
     if ((size_t)l >= m->lstm_sbk.size() || m->lstm_sbk[l].sb_off < 0) return false;
-    return lstm_sb_shape(m->cout(l), h, w).ok;
+    return lstm_sb_shape(m->cout(l), h, w, m->sb_terms).ok;
 }
 
 static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
@@ -1455,7 +1507,8 @@ static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int
     const PackedLayer& pl = m->lstm_sbk[l];
     float* hs = ws.hseq[l];
     const long dstride = TB * C * hw, fs = (long)B * C * hw;
-    const long sb_ns = (long)cdiv(C, 16) * hw * SB_PIX_BYTES;              // bytes of one frame's SB16 image
+    const int terms = m->sb_terms;
+    const long sb_ns = (long)cdiv(C, 16) * hw * sb_pix_bytes(terms);       // bytes of one frame's SB16 image
     const long sb_buf = 2L * B * sb_ns;                                    // one buffer: both directions
     const int dsel = m->dir_mask == 2 ? 1 : 0;
     const bool one_dir = m->dir_mask != 3;
@@ -1469,8 +1522,10 @@ static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int
         a.hsb = hsk + (st & 1) * sb_buf;
         a.hin_gs = (long)B * sb_ns;
         a.hin_ns = sb_ns;
-        a.wpk = reinterpret_cast<const unsigned short*>(m->P(pl.sb_off));
-        a.w_gs = pl.sb_sz * 2;
+        a.terms = terms;
+        a.acc_scale = m->P(pl.sh_unscale_off);
+        a.wpk = reinterpret_cast<const unsigned short*>(m->P(pl.split_off(terms)));
+        a.w_gs = pl.split_sz(terms) * 2;
         a.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
         a.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - a.gx;
         a.gx_ns = (long)4 * C * hw;
@@ -1504,7 +1559,8 @@ static int run_recurrent_steps_sb(bde_model* m, int l, int T, int B, int h, int 
     const PackedLayer& pl = m->lstm_sb[l];
     float* hs = ws.hseq[l];
     const long dstride = TB * C * hw, fs = (long)B * C * hw;
-    const long sbf = split_bf16_bytes(2L * B, C, hw) / 4;          // floats of one SB16 hidden-state buffer (both directions)
+    const int terms = m->sb_terms;
+    const long sbf = split_bf16_bytes(2L * B, C, hw, terms) / 4;   // floats of one SB16 hidden-state buffer (both directions)
     for (int st = 0; st < T; ++st) {
         const int tf = st, tb = T - 1 - st;
         ProfScope ps(m, pname("lstm", l), s);
@@ -1514,10 +1570,12 @@ static int run_recurrent_steps_sb(bde_model* m, int l, int T, int B, int h, int 
             ConvArgs a;
             memset(&a, 0, sizeof a);
             a.in = hsb_prev;
-            a.in_ns = (long)pl.sb_chunks * hw * SB_PIX_BYTES / 4;
+            a.in_ns = (long)pl.sb_chunks * hw * sb_pix_bytes(terms) / 4;
             a.in_gs = a.in_ns * B;
-            a.wpk = m->P(pl.sb_off);
-            a.w_gs = pl.sb_sz;
+            a.sb_terms = terms;
+            a.acc_scale = m->P(pl.sh_unscale_off);
+            a.wpk = m->P(pl.split_off(terms));
+            a.w_gs = pl.split_sz(terms);
             a.bias = m->P(m->zero_off_long());                       // the gates' bias rides in gx
             a.bias_gs = 0;
             a.out = ws.ghb[l];
@@ -1545,6 +1603,7 @@ static int run_recurrent_steps_sb(bde_model* m, int l, int T, int B, int h, int 
         p.hsb = reinterpret_cast<unsigned short*>(hsb_next);
         p.C = C; p.B = B; p.HW = hw;
         p.first = st == 0;
+        p.terms = terms;
         BDE_TRY(lstm_point_launch(p, s));
     }
     return BDE_OK;
@@ -1855,10 +1914,13 @@ static int run_attention_frame_win(bde_model* m, int l, const float* const* fram
         a.biasF = m->P(ab.biasF_off);
         const bool sbk = m->winblock_sb && ab.qkvS >= 0;
         if (sbk) {
-            a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(ab.qkvS));
-            a.wprojS = reinterpret_cast<const unsigned short*>(m->P(ab.projS));
-            a.wfc1S = reinterpret_cast<const unsigned short*>(m->P(ab.fc1S));
-            a.wfc2S = reinterpret_cast<const unsigned short*>(m->P(ab.fc2S));
+            const bool two = m->sb_terms == 2;
+            a.terms = two ? 2 : 3;
+            a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(two ? ab.qkvH : ab.qkvS));
+            a.wprojS = reinterpret_cast<const unsigned short*>(m->P(two ? ab.projH : ab.projS));
+            a.wfc1S = reinterpret_cast<const unsigned short*>(m->P(two ? ab.fc1H : ab.fc1S));
+            a.wfc2S = reinterpret_cast<const unsigned short*>(m->P(two ? ab.fc2H : ab.fc2S));
+            a.unscale = m->P(ab.unscaleH);
         }
         a.stamps = m->tok_stamps;
         a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw; a.pt = ph / 2; a.pl = pw / 2;
@@ -2109,11 +2171,11 @@ static int run_decoder(bde_model* m, int j, const float* in, const float* skip, 
     const PackedLayer& pl = m->dec[j];
     Workspace& ws = m->W();
     // a split-bf16 convolution reads SB16: the upsampling kernel then writes that image directly (no fp32 map, no conversion)
-    const bool to_sb = m->fuse_enc_sb && !pred_out && conv_takes_sb(m, pl, 1, N, 2 * Hs, 2 * Ws) && ws.sb &&
+    const bool to_sb = m->fuse_enc_sb && (!pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, 1, N, 2 * Hs, 2 * Ws) && ws.sb &&
                        split_bf16_bytes(N, pl.Cin, 4L * Hs * Ws) <= ws.sb_bytes;
     {
         ProfScope ps(m, pname("dec_up", j), s);
-        if (to_sb) BDE_TRY(upsample2x_sum_split(in, skip, ws.sb, N, pl.Cin, Hs, Ws, s));
+        if (to_sb) BDE_TRY(upsample2x_sum_split(in, skip, ws.sb, N, pl.Cin, Hs, Ws, m->sb_terms, s));
         else BDE_TRY(upsample2x_sum(in, skip, ws.up, Hs, Ws, (long)N * pl.Cin, s));
     }
     ConvCall d;
@@ -2643,6 +2705,13 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     }
     if (std::string(key) == "wide_fuse_qkv") { m->wide_fuse_qkv = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "sb_terms") {
+        BDE_REQUIRE(value == 2 || value == 3, "sb_terms: 2 (two fp16 terms) or 3 (three bf16 terms)");
+        if (m->sb_terms != (int)value)
+            for (auto& w : m->wslots) w.release();           // launch shapes and buffer roles depend on the format
+        m->sb_terms = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_two_streams") { m->lstm_two_streams = (int)value; return BDE_OK; }
@@ -2691,7 +2760,9 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "conv_sb") *value = m->conv_sb;
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;
     else if (k == "lstm_sbk") *value = m->use_lstm_sbk;
+    else if (k == "sb_terms") *value = m->sb_terms;
     else if (k == "packed_numel") *value = m->dev_numel;
+    else if (k == "sb_head") *value = m->head.sb_used;
     else if (k.compare(0, 3, "sb_") == 0 && k.size() >= 5 && k.back() >= '0' && k.back() - '0' < m->L) {
         // did the latest launch of that layer run as split bf16 (conv_sb.h)?  "sb_enc<l>", "sb_gx<l>", "sb_dec<j>"
         const int i = k.back() - '0';
@@ -2726,8 +2797,13 @@ int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n) {
 int bde_debug_conv_shape(int32_t ks, int32_t stride, int32_t cout, int32_t in_h, int32_t in_w, int32_t* row_tiles) {
     const int pad = ks / 2;
     const int Ho = (in_h + 2 * pad - ks) / stride + 1, Wo = (in_w + 2 * pad - ks) / stride + 1;
-    const int shape = conv_sb_pick(ks, stride, cout, in_w, Ho, Wo);
-    if (row_tiles) *row_tiles = shape == SB_NONE ? 0 : conv_sb_tile_mode(ks, stride, shape == SB_128x64 ? 64 : 128, in_w, Ho, Wo);
+    const int terms = BDE_DEFAULT_SB_TERMS;
+    const int shape = conv_sb_pick(ks, stride, cout, in_w, Ho, Wo, terms);
+    if (row_tiles) {
+        if (shape == SB_32x256T) *row_tiles = -conv_sb_tile_cols(256, Ho, Wo);          // 2-D tiles: minus the tile's columns
+        else if (shape == SB_64x128T) *row_tiles = -conv_sb_tile_cols(128, Ho, Wo);
+        else *row_tiles = shape == SB_NONE ? 0 : conv_sb_tile_mode(ks, stride, shape == SB_128x64 ? 64 : 128, in_w, Ho, Wo, terms);
+    }
     return shape;
 }
 

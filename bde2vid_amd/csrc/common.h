@@ -34,6 +34,9 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::bde::fail(BDE_ERR_ARG, __VA_ARGS__);                      \
     } while (0)
 
+// split.h: the operand format the split kernels take unless bde_set_tuning("sb_terms") says otherwise
+#define BDE_DEFAULT_SB_TERMS 2
+
 // Launch-shape overrides of one model (bde_set_tuning).  The launch helpers in the kernel headers read them through
 // a thread-local pointer that every C-ABI entry point sets to ITS model for the duration of the call, so two models
 // (or two devices) in one process do not see each other's settings.

@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "common.h"
+#include "split.h"
 
 namespace bde {
 
@@ -59,6 +60,8 @@ struct ConvArgs {
     // >0: pixel tiles are aligned to image rows (row_tiles tiles of BN pixels per row, the last one
     // partial) so a tile never straddles two rows and its halo is KS rows x (BN*S+KS-1) columns.
     int row_tiles;
+    // conv_sb.h: > 0 = 2-D pixel tiles of (BN / tile_cols) rows x tile_cols columns instead (row_tiles unused)
+    int tile_cols;
     // ---- EPI_LSTM (group = direction) ---------------------------------------------------
     const float* gx;     // [G][N][4*Ch][HW]  x-part of the gates incl. bias
     float* cstate;       // [G][N][Ch][HW]    cell state, updated in place
@@ -75,7 +78,11 @@ struct ConvArgs {
     // ---- split-bf16 output: when sb_out is set the result is stored ONLY as SB16 [G?][N][Cout/16][HW][3 terms][16] bf16
     // (conv_sb.h: the input layout of the convolution that consumes it), not as fp32 planes; Cout % 32 == 0, no residuals
     unsigned short* sb_out;
-    long sb_out_gs, sb_out_ns;   // group / frame strides in bf16 elements
+    long sb_out_gs, sb_out_ns;   // group / frame strides in 16-bit elements
+    // split format of sb_out and of a conv_sb input (split.h): 3 = three bf16 terms, 2 = two fp16 terms; *acc_scale undoes
+    // the power-of-two scale the two-term weights were packed with (it lives in the packed image beside them)
+    int sb_terms;
+    const float* acc_scale;
     int xcd_remap;               // conv_sb.h: workgroup order that keeps neighbouring tiles in one XCD's L2
     // one sweep direction per GPU (bde_split_*): the launch covers `groups` of the layer's groups, but every launch-shape
     // choice is made as if all `decide_groups` were present, so each direction computes exactly what the joint launch computes
@@ -112,21 +119,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // Row of accumulator register r inside a 32x32 tile (cdna_hip_programming.md §3).
-// x = hi + mid + lo in three bf16 terms, round to nearest even (the same arithmetic as sb_split3 of conv_sb.h)
-__device__ __forceinline__ unsigned short sb_rne_dev(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ void sb_split3_dev(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
-    hi = sb_rne_dev(x);
-    if ((__builtin_bit_cast(unsigned, x) & 0x7f800000u) == 0x7f800000u) { mid = lo = 0; return; }   // Inf / NaN ride in the leading term alone
-    const float r1 = x - __builtin_bit_cast(float, (unsigned)hi << 16);
-    mid = sb_rne_dev(r1);
-    const float r2 = r1 - __builtin_bit_cast(float, (unsigned)mid << 16);
-    lo = sb_rne_dev(r2);
-}
 // Workgroup -> (pixel tile bx, channel group by, frame z) of the batched convolutions.  The dispatcher deals consecutive
 // workgroups round-robin to the 8 XCDs, each with an L2 of its own: in the plain (x fastest) order the row tiles above and
 // below a tile -- most of its halo -- and the other channel groups of its pixels live in seven other L2s.  With `remap`
@@ -207,18 +199,27 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
                 for (int q = 0; q < RPW / 4; ++q) {
                     const int co0 = (cot0 + m) * 32 + acc_row(r0 + 4 * q, lane);
                     if (co0 >= a.Cout) continue;
-                    unsigned short hi[4], mid[4], lo[4];
+                    float v4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = fin[m][t][4 * q + i];
                         if (want_ln) v = rstd[t] * (v - mu[t] * sv[m][4 * q + i]);
-                        v = act_apply(v + bv[m][4 * q + i], a.act);
-                        sb_split3_dev(v, hi[i], mid[i], lo[i]);
+                        v4[i] = act_apply(v + bv[m][4 * q + i], a.act);
                     }
-                    unsigned short* d = sbb + ((long)(co0 >> 4) * HW + p) * 48 + (co0 & 15);
-                    *reinterpret_cast<uint2*>(d) = uint2{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16)};
-                    *reinterpret_cast<uint2*>(d + 16) = uint2{mid[0] | ((unsigned)mid[1] << 16), mid[2] | ((unsigned)mid[3] << 16)};
-                    *reinterpret_cast<uint2*>(d + 32) = uint2{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16)};
+                    if (a.sb_terms == 2) {
+                        unsigned short* d = sbb + ((long)(co0 >> 4) * HW + p) * 32 + (co0 & 15);
+                        uint2 hi, lo;
+                        split2_quad(v4, hi, lo);
+                        *reinterpret_cast<uint2*>(d) = hi;
+                        *reinterpret_cast<uint2*>(d + 16) = lo;
+                    } else {
+                        unsigned short* d = sbb + ((long)(co0 >> 4) * HW + p) * 48 + (co0 & 15);
+                        uint2 hi, mid, lo;
+                        split3_quad(v4, hi, mid, lo);
+                        *reinterpret_cast<uint2*>(d) = hi;
+                        *reinterpret_cast<uint2*>(d + 16) = mid;
+                        *reinterpret_cast<uint2*>(d + 32) = lo;
+                    }
                 }
         }
         return;

@@ -1,22 +1,19 @@
-// Batched direct convolution with fp32-equivalent arithmetic on the bf16 matrix cores ("split bf16", bf16x3).
+// Batched direct convolution with fp32-equivalent arithmetic on the 16-bit matrix cores (split operands, split.h).
 //
 // The convolutions of the path are compute-bound on the fp32 matrix rate (64 FLOP/clk/SIMD), and that rate is 1/16 of the
-// bf16 one.  An fp32 value is the exact sum of three bf16 terms (hi + mid + lo, 8 + 8 + 8 significant bits), so an fp32
-// product is the sum of nine bf16 x bf16 products, each exact in fp32; dropping the three whose relative size is
-// <= 2^-24 leaves six bf16 MFMAs per fp32 MFMA-equivalent:
-//     a b  ~=  a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1          (error per product <= 3 * 2^-24 |a b|, fp32 accumulate)
-// = 6 x 32 cycles of v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block against 8 x 64 cycles of v_mfma_f32_32x32x2_f32:
-// 2.67x the fp32 matrix rate at the accuracy of an fp32 contraction (tools/bf16_split_error.py; every parity test of the
-// fp32 kernels holds at its tolerance).  dtype of the path stays "f32": inputs, outputs and accumulation are fp32.
+// bf16 / fp16 one.  split.h writes an fp32 operand as two fp16 terms (three MFMAs per fp32 block: 5.3x the fp32 matrix rate) or
+// as three bf16 terms (six MFMAs: 2.67x; fp32's exponent range), at the accuracy of an fp32 contraction either way
+// (tools/ubench/mfma_f16_probe.hip, tools/bf16_split_error.py; every parity test of the fp32 kernels holds at its tolerance).
+// dtype of the path stays "f32": inputs, outputs and accumulation are fp32.  TERMS is a template parameter of every kernel here.
 //
 // Operands:
-//   activations  SB16 [N][ceil(C/16)][H][W][3 terms][16 channels] bf16 (96 B per pixel and 16-channel chunk), written by
-//                split_bf16_kernel from the fp32 NCHW planes the rest of the path keeps;
+//   activations  SB16 [N][ceil(C/16)][H][W][TERMS][16 channels] (32 TERMS bytes per pixel and 16-channel chunk), written by
+//                split_bf16_kernel from fp32 NCHW planes or directly by the producing kernel's epilogue;
 //   weights      split once at pack time, in A-fragment order of the 32x32x16 MFMA:
 //                [co tile 32][chunk][tap][term][64 lanes][8]: lane l = W[32 tile + (l & 31)][16 chunk + 8 (l >> 5) + j][tap].
 // Workgroup = WM x WN waves, a wave = MT x NT tiles of 32 output channels x 32 pixels; per 16-channel chunk the halo tile of
 // the workgroup's BN pixels is staged by LDS-DMA (global_load_lds_dwordx4: no staging registers, which is what lets the
-// weight fragments be double-buffered and a third workgroup fit a CU; 112-byte pixel pitch: conflict-free 16-byte
+// weight fragments be double-buffered and a third workgroup fit a CU; pixel pitch 32 TERMS + 16 bytes: conflict-free 16-byte
 // fragment reads), the workgroups of a CU covering each other's staging; weight fragments go L2 -> registers two (3x3) or four (5x5)
 // taps ahead.
 // Epilogue = generic_epilogue of conv_mfma.h (bias, ReLU / ReLU6, residuals; same D layout as the fp32 32x32x2 MFMA).
@@ -26,34 +23,12 @@
 
 namespace bde {
 
-typedef __bf16 sb8 __attribute__((ext_vector_type(8)));     // 8 bf16 = one MFMA operand fragment (16 bytes)
-typedef float sbf4 __attribute__((ext_vector_type(4)));
+// (formats, splits and the MFMA wrappers: split.h)
 
-__host__ __device__ __forceinline__ unsigned short sb_bf16_rne(float x) {
-    unsigned u = __builtin_bit_cast(unsigned, x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__host__ __device__ __forceinline__ float sb_bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
-// x = hi + mid + lo with three bf16 terms (exact for every finite fp32 x whose low term does not underflow; a finite x
-// that rounds up to an infinite bf16 -- |x| > 3.39e38 -- keeps hi = Inf with mid = -Inf: out of range for this scheme)
-__host__ __device__ __forceinline__ void sb_split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
-    hi = sb_bf16_rne(x);
-    // Inf / NaN ride in the leading term alone (Inf - Inf would put a NaN into the second term of an infinite value)
-    if ((__builtin_bit_cast(unsigned, x) & 0x7f800000u) == 0x7f800000u) { mid = lo = 0; return; }
-    const float r1 = x - sb_bf16_to_f32(hi);
-    mid = sb_bf16_rne(r1);
-    const float r2 = r1 - sb_bf16_to_f32(mid);
-    lo = sb_bf16_rne(r2);
-}
-
-constexpr int SB_PIX_BYTES = 96;       // 3 terms x 16 channels x 2 B
-constexpr int SB_LDS_PITCH = 112;      // + 16 B: sixteen lanes' 16-byte reads land in sixteen different bank groups
-
-#ifdef BDE_CONV_TU
-// fp32 [N][C][H][W] -> SB16 [N][C16][H][W][3][16].  grid (ceil(HW / 128), C16, N), 256 threads: thread = (pixel, half of
-// the chunk), a wave = 64 consecutive pixels of one half: 8 plane loads of 256 contiguous bytes each, three 16-byte stores.
+#ifdef BDE_SB_TU
+// fp32 [N][C][H][W] -> SB16 [N][C16][H][W][terms][16].  grid (ceil(HW / 128), C16, N), 256 threads: thread = (pixel, half of
+// the chunk), a wave = 64 consecutive pixels of one half: 8 plane loads of 256 contiguous bytes each, one 16-byte store per term.
+template <int TERMS>
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, long HW) {
     const int half = threadIdx.x >> 7;
     const long p = (long)blockIdx.x * 128 + (threadIdx.x & 127);
@@ -61,32 +36,34 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     const long n = blockIdx.z;
     if (p >= HW) return;
     const int C16 = gridDim.y;
-    unsigned short t[3][8];
+    unsigned short t[8][TERMS];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c16 * 16 + half * 8 + j;
         const float x = c < C ? in[(n * C + c) * HW + p] : 0.f;
-        sb_split3(x, t[0][j], t[1][j], t[2][j]);
+        sb_split_dev<TERMS>(x, t[j]);
     }
-    unsigned short* o = out + (((n * C16 + c16) * HW + p) * 3) * 16 + half * 8;
+    unsigned short* o = out + (((n * C16 + c16) * HW + p) * TERMS) * 16 + half * 8;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < TERMS; ++k) {
         uint4 v;
-        v.x = t[k][0] | ((unsigned)t[k][1] << 16);
-        v.y = t[k][2] | ((unsigned)t[k][3] << 16);
-        v.z = t[k][4] | ((unsigned)t[k][5] << 16);
-        v.w = t[k][6] | ((unsigned)t[k][7] << 16);
+        v.x = t[0][k] | ((unsigned)t[1][k] << 16);
+        v.y = t[2][k] | ((unsigned)t[3][k] << 16);
+        v.z = t[4][k] | ((unsigned)t[5][k] << 16);
+        v.w = t[6][k] | ((unsigned)t[7][k] << 16);
         *reinterpret_cast<uint4*>(o + k * 16) = v;
     }
 }
-int split_bf16(const float* in, void* out, long N, int C, long HW, hipStream_t s) {
+int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, hipStream_t s) {
     const int C16 = cdiv(C, 16);
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdivl(HW, 128), C16, (unsigned)N), dim3(256), 0, s, in, (unsigned short*)out, C, HW);
+    const dim3 grid((unsigned)cdivl(HW, 128), C16, (unsigned)N);
+    if (terms == 2) hipLaunchKernelGGL(split_bf16_kernel<2>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, HW);
+    else hipLaunchKernelGGL(split_bf16_kernel<3>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, HW);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 #else
-int split_bf16(const float* in, void* out, long N, int C, long HW, hipStream_t s);   // conv_tu.hip
+int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, hipStream_t s);   // sb_tu.hip
 #endif
 // ConvLSTM pointwise tail for the split-bf16 recurrent step (submodules.py:320-332): gates = gx (x-part incl. bias) + gh
 // (h-part, from conv_sb_kernel; nullptr at the first step, h = 0), chunk order i, f, o, g; c = sigma(f) c + sigma(i) tanh(g);
@@ -97,15 +74,17 @@ struct LstmPointArgs {
     const float* gh;       // [2][B][4C][HW] or nullptr
     float* cstate;         // [2][B][C][HW]
     float* hout;           // direction g, frame n: hout + g * h_gs + n * h_ns, [C][HW]
-    unsigned short* hsb;   // [2][B][C16][HW][3][16]
+    unsigned short* hsb;   // [2][B][C16][HW][terms][16]
     long gx_gs, gx_ns, h_gs, h_ns;
     int C, B;
     long HW;
     int first;             // 1: c_prev = 0 as well
+    int terms;
 };
-#ifdef BDE_CONV_TU
+#ifdef BDE_SB_TU
 __device__ __forceinline__ float sb_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 __device__ __forceinline__ float sb_tanh(float v) { return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -2.8853900817779268f)) - 1.f; }
+template <int TERMS>
 __global__ __launch_bounds__(256) void lstm_point_kernel(const LstmPointArgs a) {
     const int half = threadIdx.x & 1;
     const long p = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
@@ -117,7 +96,7 @@ __global__ __launch_bounds__(256) void lstm_point_kernel(const LstmPointArgs a) 
     const float* gh = a.gh ? a.gh + ((long)(g * a.B + n) * 4 * C) * a.HW : nullptr;
     float* cs = a.cstate + ((long)(g * a.B + n) * C) * a.HW;
     float* ho = a.hout + g * a.h_gs + n * a.h_ns;
-    unsigned short t[3][8];
+    unsigned short t[8][TERMS];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ch = c16 * 16 + half * 8 + j;
@@ -132,36 +111,40 @@ __global__ __launch_bounds__(256) void lstm_point_kernel(const LstmPointArgs a) 
             cs[o] = c;
             ho[o] = h;
         }
-        sb_split3(h, t[0][j], t[1][j], t[2][j]);
+        sb_split_dev<TERMS>(h, t[j]);
     }
-    unsigned short* o = a.hsb + ((((long)(g * a.B + n) * C16 + c16) * a.HW + p) * 3) * 16 + half * 8;
+    unsigned short* o = a.hsb + ((((long)(g * a.B + n) * C16 + c16) * a.HW + p) * TERMS) * 16 + half * 8;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < TERMS; ++k) {
         uint4 v;
-        v.x = t[k][0] | ((unsigned)t[k][1] << 16);
-        v.y = t[k][2] | ((unsigned)t[k][3] << 16);
-        v.z = t[k][4] | ((unsigned)t[k][5] << 16);
-        v.w = t[k][6] | ((unsigned)t[k][7] << 16);
+        v.x = t[0][k] | ((unsigned)t[1][k] << 16);
+        v.y = t[2][k] | ((unsigned)t[3][k] << 16);
+        v.z = t[4][k] | ((unsigned)t[5][k] << 16);
+        v.w = t[6][k] | ((unsigned)t[7][k] << 16);
         *reinterpret_cast<uint4*>(o + k * 16) = v;
     }
 }
 int lstm_point_launch(const LstmPointArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(lstm_point_kernel, dim3((unsigned)cdivl(a.HW, 128), cdiv(a.C, 16), 2 * a.B), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)cdivl(a.HW, 128), cdiv(a.C, 16), 2 * a.B);
+    if (a.terms == 2) hipLaunchKernelGGL(lstm_point_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lstm_point_kernel<3>, grid, dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 #else
-int lstm_point_launch(const LstmPointArgs& a, hipStream_t s);   // conv_tu.hip
+int lstm_point_launch(const LstmPointArgs& a, hipStream_t s);   // sb_tu.hip
 #endif
 
-static inline long split_bf16_bytes(long N, int C, long HW) { return N * cdiv(C, 16) * HW * SB_PIX_BYTES; }
+// bytes of an SB16 image; buffers are sized for the wider format so the format can change without reallocation
+static inline long split_bf16_bytes(long N, int C, long HW, int terms = 3) { return N * cdiv(C, 16) * HW * sb_pix_bytes(terms); }
 
 // a.in = SB16 activations (as float*), a.wpk = split packed weights; group / frame strides of `in` in BYTES / 4 (floats).
 // DB: two halo buffers in LDS, the next chunk's DMA in flight during the MFMAs of the current one -- for the small launches
 // of the recurrent step, where a CU holds one or two workgroups and nobody else covers the staging.
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int SB_PIX_BYTES = sb_pix_bytes(TERMS), SB_LDS_PITCH = sb_lds_pitch(TERMS), SLOTS = sb_lds_slots(TERMS);
     constexpr int BN = WN * NT * 32;
     extern __shared__ __align__(16) unsigned char sb_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,32 +154,55 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     conv_block_coords(a.xcd_remap, bx, by, z);
     const int g = z / a.N, n = z - g * a.N;
     const int HW = a.Ho * a.Wo;
-    int p0, p_end;
-    if (a.row_tiles > 0) {
-        const int yy = bx / a.row_tiles, xt = bx - yy * a.row_tiles;
-        p0 = yy * a.Wo + xt * BN;
-        p_end = min(p0 + BN, (yy + 1) * a.Wo);
-    } else {
-        p0 = bx * BN;
-        p_end = min(p0 + BN, HW);
-    }
-    const int p_last = p_end - 1;
-    const int y_first = p0 / a.Wo, y_last = p_last / a.Wo;
-    const bool one_row = (y_first == y_last);
-    const int x_first = p0 - y_first * a.Wo;
-    const int iy0 = y_first * STRIDE - PAD;
-    const int ix0 = one_row ? x_first * STRIDE - PAD : -PAD;
-    const int R = (y_last - y_first) * STRIDE + KS;
-    const int IW = one_row ? (p_last - p0) * STRIDE + KS : a.Win + 2 * PAD;
-
+    int p_end, iy0, ix0, R, IW;
     int boff[NT], pix[NT];
+    if (a.tile_cols > 0) {
+        // 2-D pixel tile of tile_rows x tile_cols output pixels (= BN): the halo is a small rectangle instead of KS whole
+        // row segments.  Pixel q of the tile = (q / tile_cols, q % tile_cols); lanes outside the image compute on halo zeros
+        // and store nothing (pix = HW).
+        const int TC = a.tile_cols, TR = BN / TC;
+        const int tiles_x = (a.Wo + TC - 1) / TC;
+        const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+        const int y0 = ty * TR, x0 = tx * TC;
+        p_end = HW;
+        iy0 = y0 * STRIDE - PAD;
+        ix0 = x0 * STRIDE - PAD;
+        R = (TR - 1) * STRIDE + KS;
+        IW = (TC - 1) * STRIDE + KS;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int p = p0 + (wn * NT + t) * 32 + (lane & 31);
-        pix[t] = p;
-        const int pc = min(p, p_last);
-        const int y = pc / a.Wo, x = pc - y * a.Wo;
-        boff[t] = ((y - y_first) * STRIDE * IW + (x * STRIDE - PAD - ix0)) * SB_LDS_PITCH + hl * 16;
+        for (int t = 0; t < NT; ++t) {
+            const int q = (wn * NT + t) * 32 + (lane & 31);
+            const int qy = q / TC, qx = q - qy * TC;
+            const int y = y0 + qy, x = x0 + qx;
+            pix[t] = (y < a.Ho && x < a.Wo) ? y * a.Wo + x : HW;
+            boff[t] = (qy * STRIDE * IW + qx * STRIDE) * SB_LDS_PITCH + hl * 16;
+        }
+    } else {
+        int p0;
+        if (a.row_tiles > 0) {
+            const int yy = bx / a.row_tiles, xt = bx - yy * a.row_tiles;
+            p0 = yy * a.Wo + xt * BN;
+            p_end = min(p0 + BN, (yy + 1) * a.Wo);
+        } else {
+            p0 = bx * BN;
+            p_end = min(p0 + BN, HW);
+        }
+        const int p_last = p_end - 1;
+        const int y_first = p0 / a.Wo, y_last = p_last / a.Wo;
+        const bool one_row = (y_first == y_last);
+        const int x_first = p0 - y_first * a.Wo;
+        iy0 = y_first * STRIDE - PAD;
+        ix0 = one_row ? x_first * STRIDE - PAD : -PAD;
+        R = (y_last - y_first) * STRIDE + KS;
+        IW = one_row ? (p_last - p0) * STRIDE + KS : a.Win + 2 * PAD;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int p = p0 + (wn * NT + t) * 32 + (lane & 31);
+            pix[t] = p;
+            const int pc = min(p, p_last);
+            const int y = pc / a.Wo, x = pc - y * a.Wo;
+            boff[t] = ((y - y_first) * STRIDE * IW + (x * STRIDE - PAD - ix0)) * SB_LDS_PITCH + hl * 16;
+        }
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -210,21 +216,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     const long plane = (long)a.Hs * a.Ws * SB_PIX_BYTES;                  // bytes of one 16-channel chunk of a frame
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + (g * a.in_gs + n * a.in_ns) * 4;
     // Halo staging by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no staging registers): the
-    // tile is R * IW pixels x 7 sixteen-byte slots (6 of data + the pad slot); block b = 64 consecutive slots = 1 KiB of LDS
+    // tile is R * IW pixels x SLOTS sixteen-byte slots (2 per term + the pad slot); block b = 64 consecutive slots = 1 KiB of LDS
     // = one wave instruction, the waves take blocks wave, wave + NW, ...  A lane's source is its pixel's piece, or 16 bytes
     // of zeros for pixels outside the image and for the pad slot.
     constexpr int NW = WM * WN;
-    const int nslots = R * IW * 7;
+    const int nslots = R * IW * SLOTS;
     const int nblk = (nslots + 63) >> 6;
     unsigned goff[MAXI];
     unsigned vmask = 0;
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
         const int i = (wave + it * NW) * 64 + lane;
-        const int px = i / 7, q = i - px * 7;
+        const int px = i / SLOTS, q = i - px * SLOTS;
         const int r = px / IW, c = px - r * IW;
         const int iy = iy0 + r, ix = ix0 + c;
-        const bool ok = i < nslots && q < 6 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const bool ok = i < nslots && q < SLOTS - 1 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         goff[it] = ok ? (unsigned)((iy * a.Ws + ix) * SB_PIX_BYTES + q * 16) : 0u;
         if (ok) vmask |= 1u << it;
     }
@@ -244,13 +250,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             }
         }
     };
-    // weight fragments: [co tile][chunk][tap][term][64][8] bf16
+    // weight fragments: [co tile][chunk][tap][term][64][8] x 16 bit
     const int cot0 = (by * WM + wm) * MT;
     const int ncot = (a.Cout + 31) / 32;
     const sb8* wfr[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-        wfr[m] = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) + ((long)min(cot0 + m, ncot - 1) * C16 * TAPS * 3) * 64 + lane;
+        wfr[m] = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) + ((long)min(cot0 + m, ncot - 1) * C16 * TAPS * TERMS) * 64 + lane;
 
     // Weight fragments run PF taps ahead of the MFMAs that use them, in a ring of RING = PF + 1 register sets; the taps
     // of a chunk are a whole number of ring turns, so the ring position of a tap is a compile-time constant and the
@@ -259,14 +265,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     constexpr int RING = (TAPS % 3 == 0) ? 3 : 5, PF = RING - 1;
     static_assert(TAPS % RING == 0, "ring position of a tap must not depend on the chunk");
     const int S = C16 * TAPS;                               // (chunk, tap) pairs of the launch
-    sb8 af[RING][MT][3];
+    sb8 af[RING][MT][TERMS];
     if (DB) stage(0);                                       // BEFORE the fragment prefetch: the counted wait below relies on the DMA being older
 #pragma unroll
     for (int q = 0; q < PF; ++q)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) af[q][m][k] = wfr[m][((long)min(q, S - 1) * 3 + k) * 64];
+            for (int k = 0; k < TERMS; ++k) af[q][m][k] = wfr[m][((long)min(q, S - 1) * TERMS + k) * 64];
     for (int c16 = 0; c16 < C16; ++c16) {
         if (!DB) {
             __syncthreads();                               // every wave is done with the previous chunk's tile
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             // so the counted wait covers them and leaves the fragment ring in flight.  A bare s_barrier follows
             // (__syncthreads() would drain vmcnt to 0 and the ring with it); LDS reads of the other buffer were waited
             // for by the MFMAs that consumed them.
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PF * MT) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TERMS * PF * MT) : "memory");
             __builtin_amdgcn_s_barrier();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -294,36 +300,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) af[nxt][m][k] = wfr[m][(sp * 3 + k) * 64];
+                    for (int k = 0; k < TERMS; ++k) af[nxt][m][k] = wfr[m][(sp * TERMS + k) * 64];
             }
             const int ky = tap / KS, kx = tap - ky * KS;
-            sb8 bfr[NT][3];
+            sb8 bfr[NT][TERMS];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
+                for (int k = 0; k < TERMS; ++k)
                     bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    // small terms first, the leading product last
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bfr[t][2], acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][2], bfr[t][0], acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bfr[t][1], acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bfr[t][1], acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][1], bfr[t][0], acc[m][t], 0, 0, 0);
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][m][0], bfr[t][0], acc[m][t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t) acc[m][t] = sb_mma32<TERMS>(af[cur][m], bfr[t], acc[m][t]);
         }
     }
+    const float unscale = TERMS == 2 ? a.acc_scale[0] : 1.f;     // two-term weights are packed times a power of two
     float fin[MT][NT][16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) fin[m][t][rr] = acc[m][t][rr];
+            for (int rr = 0; rr < 16; ++rr) fin[m][t][rr] = TERMS == 2 ? acc[m][t][rr] * unscale : acc[m][t][rr];
     float mu[NT], rstd[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) mu[t] = rstd[t] = 0.f;
@@ -350,7 +349,17 @@ static inline long conv_sb_halo_pixels(int KS, int STRIDE, int BN, int Win, int 
 //   SB_128x128  four waves of 32 x 128 sharing the pixel fragments (the 3x3 gate convolutions, decoder 0)
 //   SB_128x64   four waves of 32 x 64: rows that 128-pixel tiles fill badly / stride-2 halos that do not fit at 128
 //   SB_64x128   2 x 2 waves of 32 x 64 for 64 output channels (5x5 stride 1: decoder 1)
-enum { SB_NONE = 0, SB_128x128, SB_128x64, SB_64x128 };
+//   SB_32x256T  four waves of 32 channels x 64 pixels of ONE 2-D tile (5x5 stride 1, 32 output channels: decoder 2 + predI, head)
+//   SB_64x128T  2 x 2 waves of 32 x 64 on a 2-D tile (5x5 stride 2, 64 output channels: encoder 0)
+enum { SB_NONE = 0, SB_128x128, SB_128x64, SB_64x128, SB_32x256T, SB_64x128T };
+// 2-D tiles: columns per tile (rows = BN / columns) -- the fuller cover of the map, 16 columns unless 8 or 32 cover it 5 % better
+static inline int conv_sb_tile_cols(int BN, int Ho, int Wo) {
+    auto fill = [&](int tc) { const int tr = BN / tc; return (double)Ho * Wo / ((double)cdiv(Ho, tr) * tr * cdiv(Wo, tc) * tc); };
+    int best = 16;
+    for (int tc : {8, 32})
+        if (fill(tc) > fill(best) + 0.05) best = tc;
+    return best;
+}
 // pixel tiles aligned to image rows when a row is at least 3/4 of a tile (row_tiles > 0), linear over rows otherwise
 static inline int conv_sb_row_tiles(int BN, int Ho, int Wo) {
     const double fill_lin = (double)Ho * Wo / ((double)cdiv(Ho * Wo, BN) * BN);
@@ -362,10 +371,10 @@ static inline int conv_sb_row_tiles(int BN, int Ho, int Wo) {
 // -1 when the halo fits LDS neither way (two workgroups per CU, <= 24 DMA blocks per wave).  The fuller layout is tried
 // first; a 320-pixel row does not take linear 128-pixel tiles (a tile across two rows stages four full rows) but does take
 // 128 + 128 + 64.
-static inline int conv_sb_tile_mode(int KS, int stride, int BN, int Win, int Ho, int Wo) {
+static inline int conv_sb_tile_mode(int KS, int stride, int BN, int Win, int Ho, int Wo, int terms) {
     auto fits = [&](int rt) {
         const long halo = conv_sb_halo_pixels(KS, stride, BN, Win, Ho, Wo, rt);
-        return halo * SB_LDS_PITCH <= 78 * 1024 && (halo * 7 + 63) / 64 <= 4 * 24;
+        return halo * sb_lds_pitch(terms) <= 78 * 1024 && (halo * sb_lds_slots(terms) + 63) / 64 <= 4 * 24;
     };
     const int pref = conv_sb_row_tiles(BN, Ho, Wo);
     if (fits(pref)) return pref;
@@ -377,87 +386,120 @@ static inline double conv_sb_fill(int BN, int Ho, int Wo, int rt) {
 }
 // Which shape conv_sb_launch takes for this convolution (asked before the input is split).  Among the pixel-tile widths
 // that fit, the better filled one; 128 pixels reuse every weight fragment twice as often as 64, so 64 has to be 15 % fuller.
-static inline int conv_sb_pick(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
+static inline int conv_sb_pick(int KS, int stride, int Cout, int Win, int Ho, int Wo, int terms) {
     if (!((KS == 3 && stride == 1) || (KS == 5 && (stride == 1 || stride == 2)))) return SB_NONE;
-    const int m128 = conv_sb_tile_mode(KS, stride, 128, Win, Ho, Wo);
+    const int m128 = conv_sb_tile_mode(KS, stride, 128, Win, Ho, Wo, terms);
     const double f128 = m128 >= 0 ? conv_sb_fill(128, Ho, Wo, m128) : 0.0;
     if (Cout >= 128) {
-        const int m64 = conv_sb_tile_mode(KS, stride, 64, Win, Ho, Wo);
+        const int m64 = conv_sb_tile_mode(KS, stride, 64, Win, Ho, Wo, terms);
         const double f64 = m64 >= 0 ? 0.85 * conv_sb_fill(64, Ho, Wo, m64) : 0.0;
         if (f128 < 0.6 && f64 < 0.6 * 0.85) return SB_NONE;
         return f128 >= f64 ? SB_128x128 : SB_128x64;
     }
     if (Cout == 64 && KS == 5 && stride == 1 && f128 >= 0.6) return SB_64x128;
+    if (Cout == 64 && KS == 5 && stride == 2 && Ho >= 16 && Wo >= 16) return SB_64x128T;
+    if (Cout == 32 && KS == 5 && stride == 1 && Ho >= 16 && Wo >= 16) return SB_32x256T;
     return SB_NONE;
 }
-static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, int Wo) {
-    return conv_sb_pick(KS, stride, Cout, Win, Ho, Wo) != SB_NONE;
+static inline bool conv_sb_fits(int KS, int stride, int Cout, int Win, int Ho, int Wo, int terms) {
+    return conv_sb_pick(KS, stride, Cout, Win, Ho, Wo, terms) != SB_NONE;
 }
 
-#ifdef BDE_CONV_TU
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB>
+#ifdef BDE_SB_TU
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB, int TERMS>
 static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long halo_px) {
     constexpr int BN = WN * NT * 32;
-    const size_t lds = (DB ? 2 : 1) * (((size_t)halo_px * 7 + 63) / 64 * 1024);   // whole 1-KiB DMA blocks (7 slots per pixel)
-    auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI, DB>;
+    const size_t lds = (DB ? 2 : 1) * (((size_t)halo_px * sb_lds_slots(TERMS) + 63) / 64 * 1024);   // whole 1-KiB DMA blocks
+    auto kern = conv_sb_kernel<KS, STRIDE, MT, NT, WM, WN, MAXI, DB, TERMS>;
     static unsigned char raised[BDE_MAX_DEVICES];
     if (lds > 64 * 1024) BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
     dim3 grid(a.row_tiles > 0 ? a.Ho * a.row_tiles : cdiv(a.Ho * a.Wo, BN), cdiv(a.Cout, WM * MT * 32), G * a.N);
+    if (a.tile_cols > 0) grid.x = cdiv(a.Wo, a.tile_cols) * cdiv(a.Ho, BN / a.tile_cols);
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TERMS>
 static int conv_sb_launch_shape(ConvArgs a, int G, hipStream_t stream, bool* launched) {
     constexpr int BN = WN * NT * 32;
+    constexpr int SB_LDS_PITCH = sb_lds_pitch(TERMS);
     *launched = false;
-    const int best_rt = conv_sb_tile_mode(KS, STRIDE, BN, a.Win, a.Ho, a.Wo);
+    const int best_rt = conv_sb_tile_mode(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, TERMS);
     if (best_rt < 0) return BDE_OK;
     a.row_tiles = best_rt;
     const long halo = conv_sb_halo_pixels(KS, STRIDE, BN, a.Win, a.Ho, a.Wo, best_rt);
-    const long blocks = (halo * 7 + 63) / 64;                               // 1-KiB DMA blocks of the tile
+    const long blocks = (halo * sb_lds_slots(TERMS) + 63) / 64;             // 1-KiB DMA blocks of the tile
     const long per_wave = (blocks + WM * WN - 1) / (WM * WN);
     if (halo * SB_LDS_PITCH > 78 * 1024 || per_wave > 24) return BDE_OK;    // (two workgroups per CU) else the fp32 kernels
     *launched = true;
     // few workgroups (the recurrent step): double-buffered halo, one workgroup per CU covers its own staging
     const long wgs = (long)(best_rt > 0 ? a.Ho * best_rt : cdiv(a.Ho * a.Wo, BN)) * cdiv(a.Cout, WM * MT * 32) * G * a.N;
     if (KS == 3 && wgs <= 768 && halo * SB_LDS_PITCH * 2 <= 150 * 1024) {
-        if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, true>(a, G, stream, halo);
-        if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, true>(a, G, stream, halo);
+        if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, true, TERMS>(a, G, stream, halo);
+        if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, true, TERMS>(a, G, stream, halo);
     }
-    if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, false>(a, G, stream, halo);
-    if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, false>(a, G, stream, halo);
-    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 24, false>(a, G, stream, halo);
+    if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, false, TERMS>(a, G, stream, halo);
+    if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, false, TERMS>(a, G, stream, halo);
+    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 24, false, TERMS>(a, G, stream, halo);
 }
 
-template <int KS, int STRIDE>
+// 2-D pixel tiles (conv_sb_kernel, a.tile_cols > 0)
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TERMS>
+static int conv_sb_launch_2d(ConvArgs a, int G, hipStream_t stream, bool* launched) {
+    constexpr int BN = WN * NT * 32;
+    *launched = false;
+    a.row_tiles = 0;
+    a.tile_cols = conv_sb_tile_cols(BN, a.Ho, a.Wo);
+    const int TR = BN / a.tile_cols;
+    const long halo = (long)((TR - 1) * STRIDE + KS) * ((a.tile_cols - 1) * STRIDE + KS);
+    const long blocks = (halo * sb_lds_slots(TERMS) + 63) / 64;
+    const long per_wave = (blocks + WM * WN - 1) / (WM * WN);
+    if (halo * sb_lds_pitch(TERMS) > 78 * 1024 || per_wave > 24) return BDE_OK;
+    *launched = true;
+    if (per_wave <= 8) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 8, false, TERMS>(a, G, stream, halo);
+    if (per_wave <= 16) return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 16, false, TERMS>(a, G, stream, halo);
+    return conv_sb_launch_t<KS, STRIDE, MT, NT, WM, WN, 24, false, TERMS>(a, G, stream, halo);
+}
+
+template <int KS, int STRIDE, int TERMS>
 static int conv_sb_launch_ks(const ConvArgs& a, int G, hipStream_t stream, bool* launched) {
     // SB_128x128: four waves of 32 channels x 128 pixels share the pixel fragments through LDS and each stream their own
     // weight fragments (12 KB per tap and workgroup from L2); 2 x 2 waves of 64 x 64 fetch every weight fragment twice
     // (24 KB per tap), which is what saturated the L1 return path.
-    const int shape = conv_sb_pick(KS, STRIDE, a.Cout, a.Win, a.Ho, a.Wo);
+    const int shape = conv_sb_pick(KS, STRIDE, a.Cout, a.Win, a.Ho, a.Wo, TERMS);
     if (shape == SB_128x128) {
-        if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2>(a, G, stream, launched);
-        return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1>(a, G, stream, launched);
+        if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2, TERMS>(a, G, stream, launched);
+        return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1, TERMS>(a, G, stream, launched);
     }
-    if (shape == SB_128x64) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 4, 1>(a, G, stream, launched);
-    if constexpr (KS == 5 && STRIDE == 1)
-        if (shape == SB_64x128) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 2, 2>(a, G, stream, launched);
+    if (shape == SB_128x64) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 4, 1, TERMS>(a, G, stream, launched);
+    if constexpr (KS == 5 && STRIDE == 1) {
+        if (shape == SB_64x128) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 2, 2, TERMS>(a, G, stream, launched);
+        if (shape == SB_32x256T) return conv_sb_launch_2d<KS, STRIDE, 1, 2, 1, 4, TERMS>(a, G, stream, launched);
+    }
+    if constexpr (KS == 5 && STRIDE == 2)
+        if (shape == SB_64x128T) return conv_sb_launch_2d<KS, STRIDE, 1, 2, 2, 2, TERMS>(a, G, stream, launched);
     *launched = false;
     return BDE_OK;
 }
 
+// a.sb_terms = the format of a.in / a.wpk (and of a.sb_out)
 int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched) {
     *launched = false;
-    if (KS == 3 && stride == 1) return conv_sb_launch_ks<3, 1>(a, G, stream, launched);
-    if (KS == 5 && stride == 1) return conv_sb_launch_ks<5, 1>(a, G, stream, launched);
-    if (KS == 5 && stride == 2) return conv_sb_launch_ks<5, 2>(a, G, stream, launched);
+    if (a.sb_terms == 2) {
+        if (KS == 3 && stride == 1) return conv_sb_launch_ks<3, 1, 2>(a, G, stream, launched);
+        if (KS == 5 && stride == 1) return conv_sb_launch_ks<5, 1, 2>(a, G, stream, launched);
+        if (KS == 5 && stride == 2) return conv_sb_launch_ks<5, 2, 2>(a, G, stream, launched);
+        return BDE_OK;
+    }
+    if (KS == 3 && stride == 1) return conv_sb_launch_ks<3, 1, 3>(a, G, stream, launched);
+    if (KS == 5 && stride == 1) return conv_sb_launch_ks<5, 1, 3>(a, G, stream, launched);
+    if (KS == 5 && stride == 2) return conv_sb_launch_ks<5, 2, 3>(a, G, stream, launched);
     return BDE_OK;
 }
 #else
-int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched);   // conv_tu.hip
+int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched);   // sb_tu.hip
 #endif
 
 }  // namespace bde

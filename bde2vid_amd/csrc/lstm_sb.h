@@ -34,7 +34,7 @@ namespace bde {
 struct LstmSbArgs {
     const unsigned char* hin;       // SB16 image of h_prev, group g, frame n: hin + g * hin_gs + n * hin_ns (bytes)
     long hin_gs, hin_ns;
-    const unsigned short* wpk;      // split weights [G][row tile][chunk][tap][3][64][8]
+    const unsigned short* wpk;      // split weights [G][row tile][chunk][tap][terms][64][8]
     long w_gs;                      // in bf16 elements
     const float* gx;                // x-part of the gates incl. bias, gate-major [4 Ch][HW]: gx + g * gx_gs + n * gx_ns
     long gx_gs, gx_ns;
@@ -46,6 +46,8 @@ struct LstmSbArgs {
     const float* zeros;             // >= 16 bytes of zeros (source of out-of-image halo pixels)
     int B, Ch, H, W;
     int first;                      // 1: h_prev = c_prev = 0, no contraction
+    int terms;                      // split format of hin / hsb / wpk (split.h)
+    const float* acc_scale;         // two-term weights: -> the inverse of the power of two they were packed with (packed image)
     int TR, TC, tiles_x;            // a workgroup's pixels: TR image rows x TC columns (TR * TC <= NT * 32), tiles per row
     unsigned long long* stamps;     // diagnostics only: s_memtime per phase, [block < 64][wave < 4][8]
     int stamp_mode;                 // 1: instead, s_memrealtime start / end of every workgroup < 1000 ([wg][2])
@@ -58,9 +60,10 @@ struct LstmSbArgs {
 
 // DB: two sets of halo tiles; stage s + 1 is requested before the MFMAs of stage s (where three workgroups' worth of LDS allows:
 // the workgroups of a launch run in lockstep, so their halo waits coincide and nobody covers them).
-template <int RTW, int KW, int NT, int MAXI, bool DB>
+template <int RTW, int KW, int NT, int MAXI, bool DB, int TERMS>
 __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a) {
     static_assert(RTW * KW == 4, "four waves per workgroup");
+    constexpr int SB_PIX_BYTES = sb_pix_bytes(TERMS), SB_LDS_PITCH = sb_lds_pitch(TERMS), SLOTS = sb_lds_slots(TERMS);
     constexpr int QW = 4 / KW;                          // register groups (= hidden channels x 2) a wave finishes per tile
     extern __shared__ __align__(16) unsigned char lsb[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     };
 
     const int stages = C16 / KW;                         // chunks per part of K
-    const int nslots = IR * IW * 7;                      // 16-byte slots of one halo tile (6 of data + the pad slot per pixel)
+    const int nslots = IR * IW * SLOTS;                  // 16-byte slots of one halo tile (2 per term + the pad slot per pixel)
     const int nblk = (nslots + 63) >> 6;                 // 1-KiB DMA blocks of one tile
     const int tile_bytes = nblk * 1024;
     if (a.first) {
@@ -149,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
             const int blk = wave + it * 4;
             const int part = (int)(((float)blk + 0.5f) * inv_nblk), b_in = blk - part * nblk;
             const int i = b_in * 64 + lane;
-            const int px = i / 7, qs = i - px * 7;
+            const int px = i / SLOTS, qs = i - px * SLOTS;
             const int r = (int)(((float)px + 0.5f) * inv_iw), c = px - r * IW;      // (exact for px < 2^20; an integer division by a
             const int iy = y0 - 1 + r, ix = x0 - 1 + c;                           //  run-time divisor is ~40 instructions, MAXI times)
-            const bool ok = part < KW && i < nslots && qs < 6 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const bool ok = part < KW && i < nslots && qs < SLOTS - 1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             goff[it] = ok ? (unsigned)((iy * a.W + ix) * SB_PIX_BYTES + qs * 16) : 0u;
             if (ok) vmask |= 1u << it;
             pmask |= (unsigned long long)(part & 3) << (2 * it);
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         constexpr int TAPS = 9, RING = 3, PF = 2;
         const int S = stages * TAPS;
         const sb8* wfr = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) +
-                         (((long)min(rt, nrt - 1) * C16 + (long)kp * stages) * TAPS * 3) * 64 + lane;
-        sb8 af[RING][3];
+                         (((long)min(rt, nrt - 1) * C16 + (long)kp * stages) * TAPS * TERMS) * 64 + lane;
+        sb8 af[RING][TERMS];
 #pragma unroll
         for (int q = 0; q < PF; ++q)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) af[q][k] = wfr[((long)min(q, S - 1) * 3 + k) * 64];
+            for (int k = 0; k < TERMS; ++k) af[q][k] = wfr[((long)min(q, S - 1) * TERMS + k) * 64];
         LSB_STAMP(1);
         if (DB) stage(0);
         for (int s = 0; s < stages; ++s) {
@@ -201,25 +204,17 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                 {
                     const long sp = min(s * TAPS + tap + PF, S - 1);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) af[nxt][k] = wfr[(sp * 3 + k) * 64];
+                    for (int k = 0; k < TERMS; ++k) af[nxt][k] = wfr[(sp * TERMS + k) * 64];
                 }
                 const int ky = tap / 3, kx = tap - ky * 3;
-                sb8 bfr[NT][3];
+                sb8 bfr[NT][TERMS];
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
+                    for (int k = 0; k < TERMS; ++k)
                         bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    // small terms first, the leading product last
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[t][2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][2], bfr[t][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bfr[t][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[t][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bfr[t][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[t][0], acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t) acc[t] = sb_mma32<TERMS>(af[cur], bfr[t], acc[t]);
             }
         }
         LSB_STAMP(3);
@@ -230,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     // ---- sum over the parts of K: every wave leaves its accumulators in LDS, wave (row tile, kp) collects register groups
     //      kp * QW .. of its row tile from the KW waves of that row tile -----------------------------------------------------
     float gsum[NT][QW][4];
+    const float unscale = TERMS == 2 ? a.acc_scale[0] : 1.f;     // two-term weights are packed times a power of two
     if (KW > 1 && !a.first) {
         float* red = reinterpret_cast<float*>(lsb);      // [wave][tile][reg][64 lanes]
 #pragma unroll
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                     float s = 0.f;
 #pragma unroll
                     for (int p = 0; p < KW; ++p) s += red[(((rtl * KW + p) * NT + t) * 16 + 4 * (kp * QW + qq) + gate) * 64 + lane];
-                    gsum[t][qq][gate] = s;
+                    gsum[t][qq][gate] = TERMS == 2 ? s * unscale : s;
                 }
         __syncthreads();
     } else {
@@ -255,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 #pragma unroll
             for (int qq = 0; qq < QW; ++qq)
 #pragma unroll
-                for (int gate = 0; gate < 4; ++gate) gsum[t][qq][gate] = acc[t][4 * (kp * QW + qq) + gate];
+                for (int gate = 0; gate < 4; ++gate) gsum[t][qq][gate] = TERMS == 2 ? acc[t][4 * (kp * QW + qq) + gate] * unscale : acc[t][4 * (kp * QW + qq) + gate];
     }
 
     LSB_STAMP(5);
@@ -265,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     float* hob = a.hout + g * a.ho_gs + n * a.ho_ns;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        unsigned short t3[QW][3];
+        unsigned short t3[QW][TERMS];
         const bool live = rt_live && pix[t] >= 0;
 #pragma unroll
         for (int qq = 0; qq < QW; ++qq) {
@@ -279,12 +275,12 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                 cst[o] = c;
                 hob[o] = h;
             }
-            sb_split3_dev(live ? h : 0.f, t3[qq][0], t3[qq][1], t3[qq][2]);
+            sb_split_dev<TERMS>(live ? h : 0.f, t3[qq]);
         }
         const int q = t * 32 + (lane & 31);
-        unsigned short* d = hst + ((rtl * (NT * 32) + q) * 3) * 8 + 4 * hl + kp * QW;
+        unsigned short* d = hst + ((rtl * (NT * 32) + q) * TERMS) * 8 + 4 * hl + kp * QW;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < TERMS; ++k) {
             if (QW == 4) *reinterpret_cast<uint2*>(d + k * 8) = uint2{t3[0][k] | ((unsigned)t3[1][k] << 16), t3[2][k] | ((unsigned)t3[3][k] << 16)};
             else if (QW == 2) *reinterpret_cast<unsigned*>(d + k * 8) = t3[0][k] | ((unsigned)t3[QW - 1][k] << 16);
             else d[k * 8] = t3[0][k];
@@ -293,17 +289,17 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     __syncthreads();
     {
         unsigned char* hsbo = a.hsb + g * a.hin_gs + n * a.hin_ns;
-        const int pieces = RTW * NT * 32 * 3;                // 16-byte pieces: (row tile, pixel, term)
+        const int pieces = RTW * NT * 32 * TERMS;            // 16-byte pieces: (row tile, pixel, term)
         for (int i = tid; i < pieces; i += 256) {
-            const int k = i % 3, r2 = i / 3;
+            const int k = i % TERMS, r2 = i / TERMS;
             const int q = r2 % (NT * 32), rl = r2 / (NT * 32);
             const int py = q / a.TC, px = q - py * a.TC;
             const int rtt = by * RTW + rl;
             if (py >= tr || px >= tc || rtt >= nrt) continue;
             const long p = (long)(y0 + py) * a.W + x0 + px;
-            const uint4 v = *reinterpret_cast<const uint4*>(hst + ((rl * (NT * 32) + q) * 3 + k) * 8);
+            const uint4 v = *reinterpret_cast<const uint4*>(hst + ((rl * (NT * 32) + q) * TERMS + k) * 8);
             // chunk rtt / 2, pixel p, term k, half (rtt & 1) of the 16 channels
-            *reinterpret_cast<uint4*>(hsbo + (((long)(rtt >> 1) * HW + p) * 3 + k) * 32 + (rtt & 1) * 16) = v;
+            *reinterpret_cast<uint4*>(hsbo + (((long)(rtt >> 1) * HW + p) * TERMS + k) * 32 + (rtt & 1) * 16) = v;
         }
     }
     LSB_STAMP(6);
@@ -323,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 struct LstmSbShape { int rtw, kw, nt, TR, TC, tiles_x, tiles_y, maxi; size_t lds; bool ok, db; };
 
 // How a level's step is cut (see the header): KW parts of K per workgroup by the number of 16-channel chunks, NT by the map width.
-static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw) {
+static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw, int terms) {
     LstmSbShape s{};
     s.ok = false;
     const int C16 = Ch / 16;
@@ -337,18 +333,18 @@ static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw) {
     s.tiles_x = cdiv(W, s.TC);
     s.tiles_y = cdiv(H, s.TR);
     const long halo = (long)(s.TR + 2) * (s.TC + 2);
-    const long nblk = (halo * 7 + 63) / 64;
+    const long nblk = (halo * sb_lds_slots(terms) + 63) / 64;
     const long blocks = nblk * s.kw;
     s.maxi = (int)((blocks + 3) / 4);
     const size_t stage_b = (size_t)blocks * 1024;
     const size_t red_b = s.kw > 1 ? (size_t)4 * s.nt * 16 * 64 * 4 : 0;
-    const size_t hst_b = (size_t)s.rtw * s.nt * 32 * 3 * 16;
+    const size_t hst_b = (size_t)s.rtw * s.nt * 32 * terms * 16;
     s.db = 2 * stage_b * 3 <= 150 * 1024;                 // double-buffered halo while three workgroups still fit a CU
     s.lds = std::max((s.db ? 2 : 1) * stage_b, std::max(red_b, hst_b));
     s.ok = s.maxi <= 24 && s.lds <= 80 * 1024;            // (two workgroups per CU at least)
     return s;
 }
-static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
+static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W, int terms) {
     LstmSbShape none{};
     none.ok = false;
     if (Ch % 16 != 0 || Ch < 16) return none;
@@ -356,16 +352,16 @@ static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W) {
     // the more chunks of K, the more of them a workgroup's waves split; a map whose rows do not fill the wider tile of the
     // four-way split (LDS of its four halo tiles) falls back to the next shape
     for (int kw = C16 >= 16 ? 4 : (C16 >= 8 ? 2 : 1); kw >= 1; kw >>= 1) {
-        const LstmSbShape s = lstm_sb_shape_kw(Ch, H, W, kw);
+        const LstmSbShape s = lstm_sb_shape_kw(Ch, H, W, kw, terms);
         if (s.ok) return s;
     }
     return none;
 }
 
-#ifdef BDE_CONV_TU
-template <int RTW, int KW, int NT, int MAXI, bool DB>
+#ifdef BDE_SB_TU
+template <int RTW, int KW, int NT, int MAXI, bool DB, int TERMS>
 static int lstm_sb_launch_t(const LstmSbArgs& a, const LstmSbShape& s, int G, hipStream_t stream) {
-    auto kern = lstm_sb_step_kernel<RTW, KW, NT, MAXI, DB>;
+    auto kern = lstm_sb_step_kernel<RTW, KW, NT, MAXI, DB, TERMS>;
     static unsigned char raised[BDE_MAX_DEVICES];
     if (s.lds > 64 * 1024) BDE_HIP(raise_dynamic_lds(raised, (const void*)kern));
     dim3 grid(s.tiles_x * s.tiles_y, cdiv(a.Ch / 8, RTW), G * a.B);
@@ -373,27 +369,48 @@ static int lstm_sb_launch_t(const LstmSbArgs& a, const LstmSbShape& s, int G, hi
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
-template <int RTW, int KW, int NT>
+template <int RTW, int KW, int NT, int TERMS>
 static int lstm_sb_launch_m(const LstmSbArgs& a, const LstmSbShape& s, int G, hipStream_t stream) {
     if (s.db) {
-        if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6, true>(a, s, G, stream);
-        if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12, true>(a, s, G, stream);
-        return lstm_sb_launch_t<RTW, KW, NT, 24, true>(a, s, G, stream);
+        if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6, true, TERMS>(a, s, G, stream);
+        if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12, true, TERMS>(a, s, G, stream);
+        return lstm_sb_launch_t<RTW, KW, NT, 24, true, TERMS>(a, s, G, stream);
     }
-    if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6, false>(a, s, G, stream);
-    if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12, false>(a, s, G, stream);
-    return lstm_sb_launch_t<RTW, KW, NT, 24, false>(a, s, G, stream);
+    if (s.maxi <= 6) return lstm_sb_launch_t<RTW, KW, NT, 6, false, TERMS>(a, s, G, stream);
+    if (s.maxi <= 12) return lstm_sb_launch_t<RTW, KW, NT, 12, false, TERMS>(a, s, G, stream);
+    return lstm_sb_launch_t<RTW, KW, NT, 24, false, TERMS>(a, s, G, stream);
+}
+// the kernel lstm_sb_step_launch takes for a shape (occupancy queries)
+template <int RTW, int KW, int NT, int TERMS>
+static const void* lstm_sb_ptr_m(const LstmSbShape& s) {
+    if (s.db) {
+        if (s.maxi <= 6) return (const void*)lstm_sb_step_kernel<RTW, KW, NT, 6, true, TERMS>;
+        if (s.maxi <= 12) return (const void*)lstm_sb_step_kernel<RTW, KW, NT, 12, true, TERMS>;
+        return (const void*)lstm_sb_step_kernel<RTW, KW, NT, 24, true, TERMS>;
+    }
+    if (s.maxi <= 6) return (const void*)lstm_sb_step_kernel<RTW, KW, NT, 6, false, TERMS>;
+    if (s.maxi <= 12) return (const void*)lstm_sb_step_kernel<RTW, KW, NT, 12, false, TERMS>;
+    return (const void*)lstm_sb_step_kernel<RTW, KW, NT, 24, false, TERMS>;
+}
+static const void* lstm_sb_kernel_ptr(const LstmSbShape& s, int terms) {
+    if (terms == 2) return s.kw == 4 ? lstm_sb_ptr_m<1, 4, 3, 2>(s) : s.kw == 2 ? lstm_sb_ptr_m<2, 2, 2, 2>(s) : lstm_sb_ptr_m<4, 1, 2, 2>(s);
+    return s.kw == 4 ? lstm_sb_ptr_m<1, 4, 3, 3>(s) : s.kw == 2 ? lstm_sb_ptr_m<2, 2, 2, 3>(s) : lstm_sb_ptr_m<4, 1, 2, 3>(s);
 }
 int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream) {
-    const LstmSbShape s = lstm_sb_shape(a.Ch, a.H, a.W);
-    if (!s.ok) return fail(BDE_ERR_UNSUPPORTED, "split-bf16 recurrent step: no shape for %d channels on a %dx%d map", a.Ch, a.H, a.W);
+    const LstmSbShape s = lstm_sb_shape(a.Ch, a.H, a.W, a.terms);
+    if (!s.ok) return fail(BDE_ERR_UNSUPPORTED, "split recurrent step: no shape for %d channels on a %dx%d map", a.Ch, a.H, a.W);
     a.TR = s.TR; a.TC = s.TC; a.tiles_x = s.tiles_x;
-    if (s.kw == 4) return lstm_sb_launch_m<1, 4, 3>(a, s, G, stream);
-    if (s.kw == 2) return lstm_sb_launch_m<2, 2, 2>(a, s, G, stream);
-    return lstm_sb_launch_m<4, 1, 2>(a, s, G, stream);
+    if (a.terms == 2) {
+        if (s.kw == 4) return lstm_sb_launch_m<1, 4, 3, 2>(a, s, G, stream);
+        if (s.kw == 2) return lstm_sb_launch_m<2, 2, 2, 2>(a, s, G, stream);
+        return lstm_sb_launch_m<4, 1, 2, 2>(a, s, G, stream);
+    }
+    if (s.kw == 4) return lstm_sb_launch_m<1, 4, 3, 3>(a, s, G, stream);
+    if (s.kw == 2) return lstm_sb_launch_m<2, 2, 2, 3>(a, s, G, stream);
+    return lstm_sb_launch_m<4, 1, 2, 3>(a, s, G, stream);
 }
 #else
-int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream);   // conv_tu.hip
+int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream);   // sb_tu.hip
 #endif
 
 }  // namespace bde

@@ -61,6 +61,8 @@ struct WinArgs {
     // winblock_sb.h: the same four weight matrices as three bf16 terms in A-fragment order of the 16x16x32 MFMA,
     // [row tile 16][k-step 32][term][64 lanes][8]
     const unsigned short *wqkvS, *wprojS, *wfc1S, *wfc2S;
+    int terms;                      // split format of the four (split.h); unscale[i] undoes the packing scale of GEMM i (two terms;
+    const float* unscale;           // four floats in the packed image)
     const float* biasF;             // [16 heads][4 query tiles][10 key tiles][64 lanes][4]: a lane's four C-operand values of a score tile as one 16-byte load, log2(e) folded,
                                     // keys beyond D*49 = -1e30
     int nslots;                     // D

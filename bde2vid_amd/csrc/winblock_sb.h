@@ -42,35 +42,48 @@ constexpr int WS_HID_TERM = 4 * WS_HID_TILE;
 static_assert(WS_HID + 3 * WS_HID_TERM <= WS_ST, "hidden activations overlay K | V | Q only");
 static_assert(WS_END <= 160 * 1024, "LDS budget of one workgroup per CU");
 
-typedef float wsf2 __attribute__((ext_vector_type(2)));
-typedef __bf16 wsb2 __attribute__((ext_vector_type(2)));
-// two fp32 values -> their bf16 roundings in one dword (v_cvt_pk_bf16_f32, round to nearest even).  Inline asm on purpose: as a
-// vector conversion it seeds the SLP vectorizer, which then turns the softmax / p*v accumulators feeding it into v_pk_*_f32
+// two fp32 values -> their 16-bit roundings in one dword (round to nearest even).  Inline asm on purpose: as a vector
+// conversion it seeds the SLP vectorizer, which then turns the softmax / p*v accumulators feeding it into v_pk_*_f32
 // pairs -- 120 spilled registers in a phase that sits at the 128-register cap.
 __device__ __forceinline__ unsigned ws_pk(float a, float b) {
     unsigned d;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-// (x0, x1) = hi + mid + lo, each term a packed bf16 pair; the remainders are exact in fp32
-__device__ __forceinline__ void ws_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = ws_pk(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
-    mid = ws_pk(r0, r1);
-    const float q0 = r0 - __builtin_bit_cast(float, mid << 16), q1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
-    lo = ws_pk(q0, q1);
+__device__ __forceinline__ unsigned ws_pkh(float a, float b) {
+    unsigned d;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
-// one 16 x 16 x 32 k-step of an fp32-equivalent product: small terms first, the leading product last
-__device__ __forceinline__ f32x4 ws_mma6(const sb8 (&af)[3], const sb8 (&bf)[3], f32x4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], acc, 0, 0, 0);
-    return acc;
+__device__ __forceinline__ float ws_h_lo(unsigned d) {          // fp16 in bits 0..15 / 16..31 of a dword -> fp32
+    float f;
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(f) : "v"(d));
+    return f;
+}
+__device__ __forceinline__ float ws_h_hi(unsigned d) {
+    float f;
+    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(d));
+    return f;
+}
+// (x0, x1) = the sum of TERMS terms, each term a packed 16-bit pair; the remainders are exact in fp32.  (No special case for
+// Inf or, with fp16 terms, |x| >= 65520: the later terms become NaN and so does the block's output -- loud, not wrong.)
+template <int TERMS>
+__device__ __forceinline__ void ws_split_pair(float x0, float x1, unsigned (&t)[TERMS]) {
+    if constexpr (TERMS == 2) {
+        t[0] = ws_pkh(x0, x1);
+        t[1] = ws_pkh(x0 - ws_h_lo(t[0]), x1 - ws_h_hi(t[0]));
+    } else {
+        t[0] = ws_pk(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, t[0] << 16), r1 = x1 - __builtin_bit_cast(float, t[0] & 0xffff0000u);
+        t[1] = ws_pk(r0, r1);
+        const float q0 = r0 - __builtin_bit_cast(float, t[1] << 16), q1 = r1 - __builtin_bit_cast(float, t[1] & 0xffff0000u);
+        t[2] = ws_pk(q0, q1);
+    }
 }
 
+// two-term weights are packed times a power of two (split.h): the accumulator of GEMM i is multiplied by a.unscale[i]
+#define WS_US(x, i) (TERMS == 2 ? (x) * a.unscale[i] : (x))
+template <int TERMS>
 __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* XT = reinterpret_cast<float*>(smem + WS_XT);
@@ -96,15 +109,15 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
     WB_STAMP(0);
     // ---- weight fragments of the first contraction, in flight while the tokens are gathered ---------
     const int rtkv = 4 + (wave & 7), rtq = wave & 3;
-    sb8 akv[2][3], aqw[2][3];
+    sb8 akv[2][TERMS], aqw[2][TERMS];
     if (!mlp_only) {
         const sb8* wq = reinterpret_cast<const sb8*>(a.wqkvS) + lane;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                akv[ks][k] = wq[((rtkv * 2 + ks) * 3 + k) * 64];
-                aqw[ks][k] = wq[((rtq * 2 + ks) * 3 + k) * 64];
+            for (int k = 0; k < TERMS; ++k) {
+                akv[ks][k] = wq[((rtkv * 2 + ks) * TERMS + k) * 64];
+                aqw[ks][k] = wq[((rtq * 2 + ks) * TERMS + k) * 64];
             }
     }
     for (int i = tid; i < 1024; i += 1024) {
@@ -222,53 +235,53 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             ST[160 + u] = __builtin_amdgcn_rsqf(var + 1e-5f);
         }
     }
-    // this thread's token as three bf16 terms into operand tile `jl` of XS (chunks g4 and 4 + g4)
+    // this thread's token as split terms into operand tile `jl` of XS (chunks g4 and 4 + g4)
     auto write_split = [&](int jl) {
-        unsigned t[3][2][4];
+        unsigned t[2][4][TERMS];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) ws_split2(xv[8 * h + 2 * p], xv[8 * h + 2 * p + 1], t[0][h][p], t[1][h][p], t[2][h][p]);
+            for (int p = 0; p < 4; ++p) ws_split_pair<TERMS>(xv[8 * h + 2 * p], xv[8 * h + 2 * p + 1], t[h][p]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < TERMS; ++k)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 *reinterpret_cast<uint4*>(XS + k * WS_XS_TERM + jl * WS_XS_TILE + (4 * h + g4) * 256 + col * 16) =
-                    uint4{t[k][h][0], t[k][h][1], t[k][h][2], t[k][h][3]};
+                    uint4{t[h][0][k], t[h][1][k], t[h][2][k], t[h][3][k]};
     };
     if (have_tok && (mlp_only || wave < 6)) write_split(wave);
     wb_sync();
     WB_STAMP(1);
 
     // B-operand fragments of token tile `jl` of an operand region (chunk stride 256 B, tile stride `tile_b`, term stride `term_b`)
-    auto load_b = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[3]) {
+    auto load_b = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[TERMS]) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g4) * 256 + col * 16);
+        for (int k = 0; k < TERMS; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g4) * 256 + col * 16);
     };
 
-    sb8 a1[2][3];                                  // fc1 fragments of this wave's row tile, fetched a phase early
+    sb8 a1[2][TERMS];                                  // fc1 fragments of this wave's row tile, fetched a phase early
     if (mlp_only) {
         const sb8* w1 = reinterpret_cast<const sb8*>(a.wfc1S) + lane;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a1[ks][k] = w1[((wave * 2 + ks) * 3 + k) * 64];
+            for (int k = 0; k < TERMS; ++k) a1[ks][k] = w1[((wave * 2 + ks) * TERMS + k) * 64];
     } else {                                       // (else, not a second if: a1 must not be live across the attention phase)
         // ---- k|v of all frames (8 row tiles x 10 token tiles) and q of the query frame (4 x 4), two passes ------------
         const int gp = wave >> 3;
         auto kv_tile = [&](int j, int jl) {
-            sb8 b0[3], b1[3];
+            sb8 b0[TERMS], b1[TERMS];
             load_b(XS, WS_XS_TERM, WS_XS_TILE, jl, 0, b0);
             load_b(XS, WS_XS_TERM, WS_XS_TILE, jl, 1, b1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = ws_mma6(akv[0], b0, acc);
-            acc = ws_mma6(akv[1], b1, acc);
+            acc = sb_mma16<TERMS>(akv[0], b0, acc);
+            acc = sb_mma16<TERMS>(akv[1], b1, acc);
             const int u = j * 16 + col;
             const float mu = ST[u], rs = ST[160 + u];
             const int row0 = rtkv * 16 + g4 * 4;           // row in q|k|v
             float val[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) val[r] = rs * (acc[r] - mu * psqkv[row0 + r]) + pbqkv[row0 + r];
+            for (int r = 0; r < 4; ++r) val[r] = rs * (WS_US(acc[r], 0) - mu * psqkv[row0 + r]) + pbqkv[row0 + r];
             if (rtkv < 8) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) KL[(j * WB_C + (row0 - 64) + r) * 16 + col] = val[r];
@@ -280,18 +293,18 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
         for (int jj = 0; jj < 3; ++jj) kv_tile(gp * 3 + jj, gp * 3 + jj);
         {
             const int j = wave >> 2;
-            sb8 b0[3], b1[3];
+            sb8 b0[TERMS], b1[TERMS];
             load_b(XS, WS_XS_TERM, WS_XS_TILE, j, 0, b0);
             load_b(XS, WS_XS_TERM, WS_XS_TILE, j, 1, b1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = ws_mma6(aqw[0], b0, acc);
-            acc = ws_mma6(aqw[1], b1, acc);
+            acc = sb_mma16<TERMS>(aqw[0], b0, acc);
+            acc = sb_mma16<TERMS>(aqw[1], b1, acc);
             const int u = j * 16 + col;
             const float mu = ST[u], rs = ST[160 + u];
             const int row0 = rtq * 16 + g4 * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                QL[(j * WB_C + row0 + r) * 16 + col] = rs * (acc[r] - mu * psqkv[row0 + r]) + pbqkv[row0 + r];
+                QL[(j * WB_C + row0 + r) * 16 + col] = rs * (WS_US(acc[r], 0) - mu * psqkv[row0 + r]) + pbqkv[row0 + r];
         }
         wb_sync();                                  // every wave is done with operand tiles 0..5
         if (wave >= 6 && wave < 10) write_split(wave - 6);
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
         WB_STAMP(2);
 
         // ---- attention: wave = head (winblock.h, unchanged but for the store of its output) ----------------------------
-        sb8 ap[2][3];                              // proj fragments (4 row tiles x 4 token tiles, one per wave)
+        sb8 ap[2][TERMS];                              // proj fragments (4 row tiles x 4 token tiles, one per wave)
         {
             const int h = wave;
             constexpr int NQT = 3;                 // query tiles on the MFMA path: queries 0..47; query 48 below
@@ -441,19 +454,19 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                 for (int i = 0; i < NQT; ++i) {
                     const float inv = 1.f / pl[i];
-                    unsigned t[3][2];
-                    ws_split2(po[i][0] * inv, po[i][1] * inv, t[0][0], t[1][0], t[2][0]);
-                    ws_split2(po[i][2] * inv, po[i][3] * inv, t[0][1], t[1][1], t[2][1]);
+                    unsigned t[2][TERMS];
+                    ws_split_pair<TERMS>(po[i][0] * inv, po[i][1] * inv, t[0]);
+                    ws_split_pair<TERMS>(po[i][2] * inv, po[i][3] * inv, t[1]);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + i * WS_XS_TILE) = uint2{t[k][0], t[k][1]};
+                    for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + i * WS_XS_TILE) = uint2{t[0][k], t[1][k]};
                 }
                 // token tile 3: column 0 = query 48, the other columns carry no attention output
                 const float inv48 = 1.f / l48;
-                unsigned t[3][2];
-                ws_split2(lane == 0 ? o48[0] * inv48 : 0.f, lane == 0 ? o48[1] * inv48 : 0.f, t[0][0], t[1][0], t[2][0]);
-                ws_split2(lane == 0 ? o48[2] * inv48 : 0.f, lane == 0 ? o48[3] * inv48 : 0.f, t[0][1], t[1][1], t[2][1]);
+                unsigned t[2][TERMS];
+                ws_split_pair<TERMS>(lane == 0 ? o48[0] * inv48 : 0.f, lane == 0 ? o48[1] * inv48 : 0.f, t[0]);
+                ws_split_pair<TERMS>(lane == 0 ? o48[2] * inv48 : 0.f, lane == 0 ? o48[3] * inv48 : 0.f, t[1]);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + 3 * WS_XS_TILE) = uint2{t[k][0], t[k][1]};
+                for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + 3 * WS_XS_TILE) = uint2{t[0][k], t[1][k]};
             }
             // proj fragments: requested only now -- the phase above sits at the 128-register cap, and a spilled register there costs
             // more than this load's latency (part of it passes in the barrier)
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) ap[ks][k] = wp[(((wave & 3) * 2 + ks) * 3 + k) * 64];
+                    for (int k = 0; k < TERMS; ++k) ap[ks][k] = wp[(((wave & 3) * 2 + ks) * TERMS + k) * 64];
             }
         }
         wb_sync();
@@ -475,9 +488,9 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             int lane_p;
             asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane_p) : "v"(tid));
             const int lane = lane_p, g4 = lane_p >> 4, col = lane_p & 15;
-            auto load_b = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[3]) {
+            auto load_b = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[TERMS]) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g4) * 256 + col * 16);
+                for (int k = 0; k < TERMS; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g4) * 256 + col * 16);
             };
             const int rt = wave & 3, i = wave >> 2;
             {
@@ -485,21 +498,21 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) a1[ks][k] = w1[((wave * 2 + ks) * 3 + k) * 64];
+                    for (int k = 0; k < TERMS; ++k) a1[ks][k] = w1[((wave * 2 + ks) * TERMS + k) * 64];
             }
-            sb8 b0[3], b1[3];
+            sb8 b0[TERMS], b1[TERMS];
             load_b(XS, WS_XS_TERM, WS_XS_TILE, i, 0, b0);
             load_b(XS, WS_XS_TERM, WS_XS_TILE, i, 1, b1);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = ws_mma6(ap[0], b0, acc);
-            acc = ws_mma6(ap[1], b1, acc);
+            acc = sb_mma16<TERMS>(ap[0], b0, acc);
+            acc = sb_mma16<TERMS>(ap[1], b1, acc);
             const int row0 = rt * 16 + g4 * 4;
             const bool carried = i == 3 && col >= 1;       // token columns 49..63: x1 = x of a pixel outside every window
             float s1 = 0.f, s2 = 0.f, x1v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float* xp = XT + (i * WB_C + row0 + r) * 16 + col;
-                const float v = carried ? *xp : *xp + acc[r] + pbproj[row0 + r];
+                const float v = carried ? *xp : *xp + WS_US(acc[r], 1) + pbproj[row0 + r];
                 *xp = v;
                 x1v[r] = v;
                 s1 += v;
@@ -515,12 +528,12 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 S2[(rt * 64 + i * 16 + col) * 2 + 1] = s2;
             }
             wb_sync();                              // every wave has read its attention-output fragments: x1 takes their place
-            unsigned t[3][2];
-            ws_split2(x1v[0], x1v[1], t[0][0], t[1][0], t[2][0]);
-            ws_split2(x1v[2], x1v[3], t[0][1], t[1][1], t[2][1]);
+            unsigned t[2][TERMS];
+            ws_split_pair<TERMS>(x1v[0], x1v[1], t[0]);
+            ws_split_pair<TERMS>(x1v[2], x1v[3], t[1]);
             unsigned char* d = XS + i * WS_XS_TILE + (rt * 2 + (g4 >> 1)) * 256 + col * 16 + (g4 & 1) * 8;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(d + k * WS_XS_TERM) = uint2{t[k][0], t[k][1]};
+            for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(d + k * WS_XS_TERM) = uint2{t[0][k], t[1][k]};
         }
         wb_sync();
         WB_STAMP(4);
@@ -530,16 +543,16 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
     int lane_q;
     asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane_q) : "v"(tid));
     const int lane2 = lane_q, g42 = lane_q >> 4, col2 = lane_q & 15;
-    auto load_b2 = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[3]) {
+    auto load_b2 = [&](const unsigned char* base, int term_b, int tile_b, int jl, int ks, sb8 (&bf)[TERMS]) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g42) * 256 + col2 * 16);
+        for (int k = 0; k < TERMS; ++k) bf[k] = *reinterpret_cast<const sb8*>(base + k * term_b + jl * tile_b + (ks * 4 + g42) * 256 + col2 * 16);
     };
-    const sb8* w2 = reinterpret_cast<const sb8*>(a.wfc2S) + ((long)(wave & 3) * 8 * 3) * 64 + lane2;   // fc2 fragments [rt][8 k-steps][3 terms]
-    sb8 wa[2][3];
+    const sb8* w2 = reinterpret_cast<const sb8*>(a.wfc2S) + ((long)(wave & 3) * 8 * TERMS) * 64 + lane2;   // fc2 fragments [rt][8 k-steps][terms]
+    sb8 wa[2][TERMS];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) wa[ks][k] = w2[(ks * 3 + k) * 64];
+        for (int k = 0; k < TERMS; ++k) wa[ks][k] = w2[(ks * TERMS + k) * 64];
     {
         const int row0 = wave * 16 + g42 * 4;
         float ss[4], bb[4];
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
         }
 #pragma unroll 2
         for (int i = 0; i < 4; ++i) {
-            sb8 b0[3], b1[3];
+            sb8 b0[TERMS], b1[TERMS];
             load_b2(XS, WS_XS_TERM, WS_XS_TILE, i, 0, b0);
             load_b2(XS, WS_XS_TERM, WS_XS_TILE, i, 1, b1);
             float s1 = 0.f, s2 = 0.f;
@@ -561,19 +574,19 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 s2 += pp.y;
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = ws_mma6(a1[0], b0, acc);
-            acc = ws_mma6(a1[1], b1, acc);
+            acc = sb_mma16<TERMS>(a1[0], b0, acc);
+            acc = sb_mma16<TERMS>(a1[1], b1, acc);
             const float mu = s1 * (1.f / WB_C);
             const float rs = __builtin_amdgcn_rsqf(fmaxf(s2 * (1.f / WB_C) - mu * mu, 0.f) + 1e-5f);
             float hv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = gelu_f(rs * (acc[r] - mu * ss[r]) + bb[r]);
-            unsigned t[3][2];
-            ws_split2(hv[0], hv[1], t[0][0], t[1][0], t[2][0]);
-            ws_split2(hv[2], hv[3], t[0][1], t[1][1], t[2][1]);
+            for (int r = 0; r < 4; ++r) hv[r] = gelu_f(rs * (WS_US(acc[r], 2) - mu * ss[r]) + bb[r]);
+            unsigned t[2][TERMS];
+            ws_split_pair<TERMS>(hv[0], hv[1], t[0]);
+            ws_split_pair<TERMS>(hv[2], hv[3], t[1]);
             unsigned char* d = HS + i * WS_HID_TILE + (wave * 2 + (g42 >> 1)) * 256 + col2 * 16 + (g42 & 1) * 8;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(d + k * WS_HID_TERM) = uint2{t[k][0], t[k][1]};
+            for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(d + k * WS_HID_TERM) = uint2{t[0][k], t[1][k]};
         }
     }
     wb_sync();
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
     // ---- x2 = x1 + fc2(hidden) (+ merged[t]): 4 row tiles x 4 token tiles, K = 256 = 8 k-steps ----------------------
     {
         const int rt = wave & 3, i = wave >> 2;
-        sb8 wb[2][3];
+        sb8 wb[2][TERMS];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kp = 0; kp < 4; ++kp) {                // two k-steps per round, the next round's fragments in flight
@@ -590,20 +603,20 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const sb8 v = w2[(((kp + 1) * 2 + ks) * 3 + k) * 64];
+                    for (int k = 0; k < TERMS; ++k) {
+                        const sb8 v = w2[(((kp + 1) * 2 + ks) * TERMS + k) * 64];
                         if (kp & 1) wa[ks][k] = v; else wb[ks][k] = v;
                     }
             }
-            sb8 b0[3], b1[3];
+            sb8 b0[TERMS], b1[TERMS];
             load_b2(HS, WS_HID_TERM, WS_HID_TILE, i, 2 * kp, b0);
             load_b2(HS, WS_HID_TERM, WS_HID_TILE, i, 2 * kp + 1, b1);
             if (kp & 1) {
-                acc = ws_mma6(wb[0], b0, acc);
-                acc = ws_mma6(wb[1], b1, acc);
+                acc = sb_mma16<TERMS>(wb[0], b0, acc);
+                acc = sb_mma16<TERMS>(wb[1], b1, acc);
             } else {
-                acc = ws_mma6(wa[0], b0, acc);
-                acc = ws_mma6(wa[1], b1, acc);
+                acc = sb_mma16<TERMS>(wa[0], b0, acc);
+                acc = sb_mma16<TERMS>(wa[1], b1, acc);
             }
         }
         const int pix = PIX[i * 16 + col2];
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             const int row0 = rt * 16 + g42 * 4;
             float y[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = XT[(i * WB_C + row0 + r) * 16 + col2] + acc[r] + pbfc2[row0 + r];
+            for (int r = 0; r < 4; ++r) y[r] = XT[(i * WB_C + row0 + r) * 16 + col2] + WS_US(acc[r], 3) + pbfc2[row0 + r];
             if (a.addres) {
                 const float4 ad = *reinterpret_cast<const float4*>(a.addres + b * a.addres_bs + (long)pix * WB_C + row0);
                 y[0] += ad.x; y[1] += ad.y; y[2] += ad.z; y[3] += ad.w;
@@ -628,12 +641,14 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 }
 
 static int winblock_sb_launch(WinArgs a, int B, hipStream_t stream) {
-    static unsigned char raised[BDE_MAX_DEVICES];
-    BDE_HIP(raise_dynamic_lds(raised, (const void*)winblock_sb_kernel));
+    static unsigned char raised2[BDE_MAX_DEVICES], raised3[BDE_MAX_DEVICES];
+    if (a.terms == 2) BDE_HIP(raise_dynamic_lds(raised2, (const void*)winblock_sb_kernel<2>));
+    else BDE_HIP(raise_dynamic_lds(raised3, (const void*)winblock_sb_kernel<3>));
     winblock_geometry(a);
     int extra = 0;
     if (a.ke > 15) { a.ke = 0; extra = cdiv(a.nA + a.nB, 64); }
-    hipLaunchKernelGGL(winblock_sb_kernel, dim3(a.nWin + extra, 1, B), dim3(1024), WS_END, stream, a);
+    if (a.terms == 2) hipLaunchKernelGGL(winblock_sb_kernel<2>, dim3(a.nWin + extra, 1, B), dim3(1024), WS_END, stream, a);
+    else hipLaunchKernelGGL(winblock_sb_kernel<3>, dim3(a.nWin + extra, 1, B), dim3(1024), WS_END, stream, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }

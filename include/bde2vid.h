@@ -151,9 +151,10 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value);
 
 /* Diagnostics: resident workgroups per CU the runtime reports for a named kernel (-1 = unknown). */
 int bde_debug_occupancy(const char* kernel);
-/* Diagnostics (host arithmetic, no GPU): the workgroup shape the split-bf16 convolution launcher picks for a ks x ks conv
- * of `cout` output channels on an in_h x in_w input: 0 = none (fp32 kernels), 1 = 128 channels x 128 pixels, 2 = 128 x 64,
- * 3 = 64 x 128; *row_tiles (may be NULL) = pixel tiles per image row, 0 = tiles run linearly over rows. */
+/* Diagnostics (host arithmetic, no GPU): the workgroup shape the split-operand convolution launcher picks, in the default
+ * operand format, for a ks x ks conv of `cout` output channels on an in_h x in_w input: 0 = none (fp32 kernels), 1 = 128
+ * channels x 128 pixels, 2 = 128 x 64, 3 = 64 x 128, 4 = 32 x 256 on 2-D pixel tiles, 5 = 64 x 128 on 2-D pixel tiles;
+ * *row_tiles (may be NULL) = pixel tiles per image row, 0 = tiles run linearly over rows, < 0 = minus the columns of a 2-D tile. */
 int bde_debug_conv_shape(int32_t ks, int32_t stride, int32_t cout, int32_t in_h, int32_t in_w, int32_t* row_tiles);
 /* Diagnostics: s_memtime stamps of the fused token kernel's phases ([block<64][wave][8]); first call
  * with host_out == NULL enables them, a later call copies n values back. */

@@ -1,9 +1,9 @@
-"""Split-bf16 convolutions (csrc/conv_sb.h): fp32-equivalent arithmetic on the bf16 matrix cores.
+"""Split-operand convolutions (csrc/conv_sb.h, csrc/split.h): fp32-equivalent arithmetic on the 16-bit matrix cores.
 
-Every parity test of the fp32 kernels also runs through them (they are on by default for the 3x3 gate convolutions); here
-their error is measured against a float64 CPU reference next to the fp32 matrix-core kernel's own, i.e. the error table of
-tools/bf16_split_error.py reproduced on the GPU: six-term split products must stay within 2x of the fp32 kernel's error
-(plain bf16 would be ~1e-3 relative)."""
+Every parity test of the fp32 kernels also runs through them (they are on by default); here their error is measured against
+a float64 CPU reference next to the fp32 matrix-core kernel's own, for both operand formats (two fp16 terms / three MFMAs,
+the default; three bf16 terms / six MFMAs): split products must stay within 2x of the fp32 kernel's error (plain bf16 or
+fp16 operands would be ~1e-3 relative)."""
 import numpy as np
 import pytest
 import torch
@@ -42,13 +42,21 @@ def test_gate_conv_error_against_float64(model_a, level, hw, N):
     m.set_tuning('conv_sb', 0)
     y32 = ops.gate_conv(m, level, xd).cpu().double()
     m.set_tuning('conv_sb', 1)
-    ysb = ops.gate_conv(m, level, xd).cpu().double()
     e32 = float((y32 - ref).abs().max()) / scale
-    esb = float((ysb - ref).abs().max()) / scale
-    print(f'level {level} {hw}: fp32 matrix cores {e32:.2e}, split bf16 (6 terms) {esb:.2e} of max|ref|')
     assert e32 <= 5e-6                                       # K up to 2304 products per output
-    assert esb <= max(2 * e32, 1e-6), f'split bf16 {esb:.2e} vs fp32 kernel {e32:.2e}'
-    assert maxabs(ysb, y32) / scale <= 4e-6
+    default_terms = m.get_info('sb_terms')
+    assert default_terms == 2
+    try:
+        for terms in (2, 3):
+            m.set_tuning('sb_terms', terms)
+            ysb = ops.gate_conv(m, level, xd).cpu().double()
+            assert m.get_info(f'sb_gx{level}') == 1
+            esb = float((ysb - ref).abs().max()) / scale
+            print(f'level {level} {hw}: fp32 matrix cores {e32:.2e}, {terms}-term split {esb:.2e} of max|ref|')
+            assert esb <= max(2 * e32, 1e-6), f'{terms}-term split {esb:.2e} vs fp32 kernel {e32:.2e}'
+            assert maxabs(ysb, y32) / scale <= 4e-6
+    finally:
+        m.set_tuning('sb_terms', default_terms)
 
 
 def test_five_by_five_split_conv_of_decoder0(model_a):
@@ -119,20 +127,20 @@ def test_producers_write_the_split_bf16_inputs(model_a):
 
 def test_workgroup_order_does_not_change_results_and_info_keys(model_a):
     """xcd_remap only permutes which workgroup computes which tile: frames are bit-identical with it on and off; get_info
-    reports which convolutions of the latest forward ran as split bf16 (config A at 184 x 240: everything but the level-0
-    encoder and the last decoder, whose epilogue carries predI)."""
+    reports which convolutions of the latest forward ran on split operands (config A at 184 x 240: all of them, the head and
+    the last decoder -- whose epilogue carries predI -- included)."""
     from tests.util import golden_inputs
     cfg, sd, m = model_a
     xs = golden_inputs(16, 1, 5, 184, 240, 4321)
     inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
     try:                                  # (16 frames: every level is over the launch-size threshold of the split-bf16 kernels)
         y1 = torch.stack(m(inp))
-        took = {k: m.get_info(k) for k in ('sb_enc0', 'sb_enc1', 'sb_enc2', 'sb_gx0', 'sb_gx1', 'sb_gx2', 'sb_dec0', 'sb_dec1', 'sb_dec2')}
+        took = {k: m.get_info(k) for k in ('sb_head', 'sb_enc0', 'sb_enc1', 'sb_enc2', 'sb_gx0', 'sb_gx1', 'sb_gx2', 'sb_dec0', 'sb_dec1', 'sb_dec2')}
         m.set_tuning('xcd_remap', 0)
         y0 = torch.stack(m(inp))
     finally:
         m.set_tuning('xcd_remap', 1)
-    assert took == dict(sb_enc0=0, sb_enc1=1, sb_enc2=1, sb_gx0=1, sb_gx1=1, sb_gx2=1, sb_dec0=1, sb_dec1=1, sb_dec2=0), took
+    assert took == dict(sb_head=1, sb_enc0=1, sb_enc1=1, sb_enc2=1, sb_gx0=1, sb_gx1=1, sb_gx2=1, sb_dec0=1, sb_dec1=1, sb_dec2=1), took
     assert torch.equal(y0, y1)
     with pytest.raises(Exception):
         m.get_info('sb_enc9')

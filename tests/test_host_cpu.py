@@ -237,8 +237,9 @@ def test_checkpoint_with_code_payload_is_rejected(tmp_path):
 
 def test_split_bf16_conv_shapes_at_the_baseline_resolutions():
     """Host arithmetic of csrc/conv_sb.h (conv_sb_pick / conv_sb_tile_mode), no GPU: which workgroup shape and pixel-tile
-    layout each batched convolution of the canonical config takes at the BASELINE resolutions (0 = fp32 kernels,
-    1 = 128 channels x 128 pixels, 2 = 128 x 64, 3 = 64 x 128; second number = tiles per image row, 0 = linear)."""
+    layout each batched convolution of the canonical config takes at the BASELINE resolutions in the default operand format
+    (two fp16 terms): 0 = fp32 kernels, 1 = 128 channels x 128 pixels, 2 = 128 x 64, 3 = 64 x 128, 4 = 32 x 256 on 2-D
+    tiles, 5 = 64 x 128 on 2-D tiles; second number = tiles per image row, 0 = linear / 2-D."""
     import ctypes as C
     from bde2vid_amd import _lib
     L = _lib.lib()
@@ -248,10 +249,10 @@ def test_split_bf16_conv_shapes_at_the_baseline_resolutions():
         return L.bde_debug_conv_shape(ks, stride, cout, h, w, C.byref(rt)), rt.value
 
     expect = {
-        (184, 240): dict(enc=[(0, 0), (2, 1), (2, 0)], gx=[(1, 1), (1, 0), (1, 0)], dec=[(1, 0), (3, 1), (0, 0)]),
-        (264, 352): dict(enc=[(0, 0), (2, 2), (2, 1)], gx=[(1, 0), (1, 0), (1, 0)], dec=[(1, 0), (3, 2), (0, 0)]),
-        (480, 640): dict(enc=[(0, 0), (2, 3), (2, 2)], gx=[(2, 5), (1, 0), (1, 0)], dec=[(2, 3), (3, 3), (0, 0)]),
-        (720, 1280): dict(enc=[(0, 0), (2, 5), (2, 3)], gx=[(1, 5), (2, 5), (1, 0)], dec=[(2, 5), (3, 5), (0, 0)]),
+        (184, 240): dict(enc=[(5, -1), (2, 1), (1, 0)], gx=[(1, 1), (1, 0), (1, 0)], dec=[(1, 0), (3, 1), (4, 2)]),
+        (264, 352): dict(enc=[(5, -1), (1, 1), (2, 0)], gx=[(1, 0), (1, 0), (1, 0)], dec=[(1, 0), (3, 2), (4, 3)]),
+        (480, 640): dict(enc=[(5, -1), (2, 3), (1, 1)], gx=[(2, 5), (1, 0), (1, 0)], dec=[(1, 0), (3, 3), (4, 5)]),
+        (720, 1280): dict(enc=[(5, -1), (2, 5), (2, 3)], gx=[(1, 5), (2, 5), (1, 0)], dec=[(2, 5), (3, 5), (4, 10)]),
     }
     chans = (64, 128, 256)
     for (H, W), e in expect.items():
