@@ -671,6 +671,10 @@ struct Workspace {
         warm = false;
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
+        // no pointer outlives its allocation: the op-level entry points test them (ws.sb, ws.hsk[l], ...) before use
+        ev = head = out = qkv = ao = x1 = hid = xa = xb = up = sb = sb2 = cat = fuse = rbA = rbX[0] = rbX[1] = zero_l = nullptr;
+        sb_bytes = sb2_bytes = 0;
+        for (auto* v : {&xenc, &gx, &hseq, &cst, &merged, &mergedT, &kvun, &kvref, &dec, &qkv0, &gur, &ghr, &gou, &gub, &hsk, &hsb, &ghb}) v->clear();
         T = B = H = W = 0;
     }
 };
@@ -691,6 +695,7 @@ struct bde_model {
     std::vector<PackedLayer> enc, gx, lstm, lstm8, dec;   // enc/gx/lstm: G=2 (fwd,bwd); lstm8 = the 8-channel-workgroup packing
     std::vector<PackedLayer> lstm_sb;                     // h-part of the gates, split-bf16 packing only (conv_sb.h)
     std::vector<PackedLayer> lstm_sbk;                    // ... gate-interleaved rows for the fused step kernel (lstm_sb.h)
+    std::vector<PackedLayer> lstm_sbx;                    // ... the same with K = [x | h]: the x-part of the gates inside the step
     std::vector<PackedLayer> gru_ur, gru_o;               // ConvGRU: h-parts of update | reset and of the candidate (G = 2)
     std::vector<PackedLayer> dec_fuse;                    // skip_concat: 1x1 fusion conv in front of decoder j
     PackedLayer pred_fuse;                                // ... and in front of predI
@@ -742,7 +747,8 @@ struct bde_model {
                                   // measured: 1208 vs 1444 frames/s pipelined, 1135 vs 1161 single stream -- half-size launches take almost as long: off
     hipStream_t dir_stream[4] = {};         // per workspace slot: the second direction's stream and its fork / join events
     hipEvent_t dir_fork[4] = {}, dir_join[4] = {};
-    int use_lstm_sbk = 1;         // recurrent step on the bf16 matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
+    int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
+    int lstm_fuse_x = 1;          // ... and the x-part of the gates in the same contraction (no batched gate convolution, no gx round trip)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
     bool prof_on = false;
@@ -891,6 +897,7 @@ static int build_packed(bde_model* m) {
     m->lstm8.assign(L, PackedLayer());
     m->lstm_sb.assign(L, PackedLayer());
     m->lstm_sbk.assign(L, PackedLayer());
+    m->lstm_sbx.assign(L, PackedLayer());
     m->dec.assign(L, PackedLayer());
     m->attn.assign(L, AttnLevel());
     m->gru_ur.assign(L, PackedLayer());
@@ -961,7 +968,20 @@ static int build_packed(bde_model* m) {
             ps.Cin = co; ps.Cout = 4 * co; ps.KS = 3; ps.G = 2;
             pack_split_bf16(ar, ps, {&gh[0], &gh[1]});
         }
-        if (co % 16 == 0) pack_lstm_sbk(ar, m->lstm_sbk[l], {&gh[0], &gh[1]});
+        if (co % 16 == 0) {
+            pack_lstm_sbk(ar, m->lstm_sbk[l], {&gh[0], &gh[1]});
+            // ... and with the x-part in the same contraction: K = [x | h], the order of the reference's stacked input
+            DenseLayer gf[2];
+            for (int d = 0; d < 2; ++d) {
+                std::string p = std::string(dirs[d]) + "." + std::to_string(l) + ".";
+                BDE_TRY(dense_conv(m, p + "recurrent_block.Gates.weight", p + "recurrent_block.Gates.bias", 4 * co, 2 * co, 0,
+                                   2 * co, 3, true, &gf[d]));
+            }
+            PackedLayer& px = m->lstm_sbx[l];
+            pack_lstm_sbk(ar, px, {&gf[0], &gf[1]});
+            px.b_off = ar.alloc(2L * 4 * co);
+            for (int d = 0; d < 2; ++d) std::copy(gf[d].bias.begin(), gf[d].bias.end(), ar.host.begin() + px.b_off + (long)d * 4 * co);
+        }
     }
     if (c.depths[L - 1] == 0) {
         // Sequential(ParseLayer, ResidualBlockNoBN x num_res_blocks) in place of the last level's attention (V5.py:77-80)
@@ -1307,6 +1327,7 @@ static bool winblock_ok(const bde_model* m, int l);
 static bool wide_ok(const bde_model* m, int l);
 static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w);
 static bool lstm_sbk_ok(const bde_model* m, int l, int h, int w);
+static bool lstm_sbx_ok(const bde_model* m, int l, int h, int w);
 
 static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     Workspace& ws = m->W();
@@ -1450,14 +1471,18 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     // the gate convolution reads its input as SB16 (conv_sb.h): the encoder conv's epilogue then writes that image directly
     // (6 B per element) and the fp32 planes + their conversion pass are skipped
     const long sb_fs = (long)cdiv(C, 16) * hw * sb_pix_bytes(m->sb_terms) / 4;   // floats of one SB16 frame
-    const bool fuse = m->fuse_enc_sb && C % 32 == 0 && conv_takes_sb(m, gx_v, 1, nf, h, w) &&
+    // (lstm_fuse_x: the recurrent step contracts [x | h] itself and reads x from that image: no gate convolution at all)
+    const bool step_x = lstm_sbx_ok(m, l, h, w);
+    const bool fuse = (step_x || (m->fuse_enc_sb && C % 32 == 0 && conv_takes_sb(m, gx_v, 1, nf, h, w))) &&
                       ws.sb2 && split_bf16_bytes(2 * TB, C, hw) <= ws.sb2_bytes;
+    BDE_REQUIRE(fuse || !step_x, "recurrent step with the x-part: no room for the split image of x");
     if (fuse) {
         e.out_sb = ws.sb2 + (long)f0 * sb_fs + (one_dir ? dsel * TB * sb_fs : 0);
         e.out_sb_gs = TB * sb_fs;
     }
     { ProfScope ps(m, pname("enc_conv", l), s); BDE_TRY(run_conv(m, e, s)); }
     m->enc[l].sb_used = enc_v.sb_used;                                   // (the launch ran on a copy / one-direction view of the layer)
+    if (step_x) { m->gx[l].sb_used = 0; return BDE_OK; }
     // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
     ConvCall gxc;
     gxc.pl = &gx_v;
@@ -1500,11 +1525,21 @@ static bool lstm_sbk_ok(const bde_model* m, int l, int h, int w) {
     return lstm_sb_shape(m->cout(l), h, w, m->sb_terms).ok;
 }
 
+// ... with the x-part of the gates in the same contraction: the encoder convolution of the level leaves x as an SB16 image
+// (its epilogue writes it, any kernel), 32 | C so that whole 32-channel tiles are written
+static bool lstm_sbx_ok(const bde_model* m, int l, int h, int w) {
+    if (!m->lstm_fuse_x || !lstm_sbk_ok(m, l, h, w)) return false;
+    const Workspace& ws = const_cast<bde_model*>(m)->W();
+    if ((size_t)l >= ws.hsk.size() || ws.hsk[l] == nullptr) return false;      // the step that will run is not the split one
+    return (size_t)l < m->lstm_sbx.size() && m->lstm_sbx[l].split_off(m->sb_terms) >= 0 && m->cout(l) % 32 == 0;
+}
+
 static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int w, hipStream_t s) {
     Workspace& ws = m->W();
     const int C = m->cout(l);
     const long TB = (long)T * B, hw = (long)h * w;
-    const PackedLayer& pl = m->lstm_sbk[l];
+    const bool step_x = lstm_sbx_ok(m, l, h, w);
+    const PackedLayer& pl = step_x ? m->lstm_sbx[l] : m->lstm_sbk[l];
     float* hs = ws.hseq[l];
     const long dstride = TB * C * hw, fs = (long)B * C * hw;
     const int terms = m->sb_terms;
@@ -1529,6 +1564,15 @@ static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int
         a.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
         a.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - a.gx;
         a.gx_ns = (long)4 * C * hw;
+        if (step_x) {
+            // x_t of both directions in ws.sb2 (run_enc_gx): [direction][TB frames], forward reads frame tf, backward frame tb
+            const unsigned char* xs = reinterpret_cast<const unsigned char*>(ws.sb2);
+            a.xin = xs + (long)tf * B * sb_ns;
+            a.xin_gs = (TB + (long)tb * B - (long)tf * B) * sb_ns;
+            a.xin_ns = sb_ns;
+            a.xchunks = C / 16;
+            a.bias = m->P(pl.b_off);
+        }
         a.cstate = ws.cst[l];
         a.c_gs = (long)B * C * hw;
         a.c_ns = (long)C * hw;
@@ -1543,6 +1587,7 @@ static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int
         if (one_dir) {                                                     // group 0 of a one-group launch = the chosen direction
             a.hin += dsel * a.hin_gs; a.hsb += dsel * a.hin_gs;
             a.wpk += dsel * a.w_gs;
+            if (step_x) { a.xin += dsel * a.xin_gs; a.bias += (long)dsel * 4 * C; }
             a.gx += dsel * a.gx_gs;
             a.cstate += dsel * a.c_gs;
             a.hout += dsel * a.ho_gs;
@@ -2704,7 +2749,12 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "wide_fuse_qkv") { m->wide_fuse_qkv = (int)value; return BDE_OK; }
-    if (std::string(key) == "conv_sb") { m->conv_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "conv_sb") {
+        if (m->conv_sb != (int)value)
+            for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it
+        m->conv_sb = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "sb_terms") {
         BDE_REQUIRE(value == 2 || value == 3, "sb_terms: 2 (two fp16 terms) or 3 (three bf16 terms)");
         if (m->sb_terms != (int)value)
@@ -2715,6 +2765,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_two_streams") { m->lstm_two_streams = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_fuse_x") { m->lstm_fuse_x = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_sbk") {
         if (m->use_lstm_sbk != (int)value)
             for (auto& w : m->wslots) w.release();
@@ -2760,6 +2811,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "conv_sb") *value = m->conv_sb;
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;
     else if (k == "lstm_sbk") *value = m->use_lstm_sbk;
+    else if (k == "lstm_fuse_x") *value = m->lstm_fuse_x;
     else if (k == "sb_terms") *value = m->sb_terms;
     else if (k == "packed_numel") *value = m->dev_numel;
     else if (k == "sb_head") *value = m->head.sb_used;

@@ -38,6 +38,12 @@ struct LstmSbArgs {
     long w_gs;                      // in bf16 elements
     const float* gx;                // x-part of the gates incl. bias, gate-major [4 Ch][HW]: gx + g * gx_gs + n * gx_ns
     long gx_gs, gx_ns;
+    // ... or the x-part contracted HERE (xchunks > 0): K = [x | h] as in the reference's stacked input (submodules.py:316-317),
+    // x's SB16 image (written by the encoder convolution's epilogue) staged like h's, the gates' bias added in the tail; gx unused
+    const unsigned char* xin;       // SB16 image of x_t, group g, frame n: xin + g * xin_gs + n * xin_ns (bytes)
+    long xin_gs, xin_ns;
+    int xchunks;                    // 16-channel chunks of x (= Ch / 16), 0 = gx mode
+    const float* bias;              // [G][4 Ch] gate-major (xchunks > 0)
     float* cstate;                  // [G][B][Ch][HW], updated in place
     long c_gs, c_ns;
     float* hout;                    // fp32 planes [Ch][HW]: hout + g * ho_gs + n * ho_ns
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     }
     const int g = z / a.B, n = z - g * a.B;
     const int HW = a.H * a.W;
-    const int C16 = a.Ch / 16, nrt = a.Ch / 8;          // 16-channel chunks of K; 32-row tiles (8 hidden channels each)
+    const int C16 = a.Ch / 16, nrt = a.Ch / 8;          // 16-channel chunks of h; 32-row tiles (8 hidden channels each)
+    const int XC = a.xchunks;                           // chunks of x ahead of them in K
+    const int KC = XC + C16;                            // chunks per row tile in the packed weights
     const int rt = by * RTW + rtl;
     const bool rt_live = rt < nrt;
     const int ty = bx / a.tiles_x, tx = bx - ty * a.tiles_x;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 
     // pointwise operands of the (channel, pixel)s this wave finishes: register groups q = kp * QW .. + QW - 1 of its row tile
     float gv[NT][QW][4], cprev[NT][QW];
-    const float* gxb = a.gx + g * a.gx_gs + n * a.gx_ns;
+    const float* gxb = XC > 0 ? a.bias + (long)g * 4 * a.Ch : a.gx + g * a.gx_gs + n * a.gx_ns;
     float* cst = a.cstate + g * a.c_gs + n * a.c_ns;
     auto epi_load = [&]() {
 #pragma unroll
@@ -128,19 +136,21 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                 const int hc = min(rt * 8 + 4 * hl + kp * QW + qq, a.Ch - 1);
                 const long o = (long)hc * HW + max(pix[t], 0);
 #pragma unroll
-                for (int gate = 0; gate < 4; ++gate) gv[t][qq][gate] = gxb[(long)gate * a.Ch * HW + o];
+                for (int gate = 0; gate < 4; ++gate) gv[t][qq][gate] = XC > 0 ? gxb[gate * a.Ch + hc] : gxb[(long)gate * a.Ch * HW + o];
                 cprev[t][qq] = a.first ? 0.f : cst[o];
             }
     };
 
-    const int stages = C16 / KW;                         // chunks per part of K
+    const int kchunks = XC + (a.first ? 0 : C16);        // chunks of K this step contracts (h_prev = 0 at the first step)
+    const int stages = kchunks / KW;                     // chunks per part of K
     const int nslots = IR * IW * SLOTS;                  // 16-byte slots of one halo tile (2 per term + the pad slot per pixel)
     const int nblk = (nslots + 63) >> 6;                 // 1-KiB DMA blocks of one tile
     const int tile_bytes = nblk * 1024;
-    if (a.first) {
+    if (kchunks == 0) {
         epi_load();
     } else {
         const unsigned char* inb = a.hin + g * a.hin_gs + n * a.hin_ns;
+        const unsigned char* xb = XC > 0 ? a.xin + g * a.xin_gs + n * a.xin_ns : inb;
         const long plane = (long)HW * SB_PIX_BYTES;
         // halo staging: KW tiles per stage (one per part of K), KW * nblk blocks dealt to the four waves
         unsigned goff[MAXI];
@@ -169,7 +179,9 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                 const int blk = wave + it * 4;
                 if (blk < KW * nblk) {
                     const int part = (int)((pmask >> (2 * it)) & 3ull);
-                    const unsigned char* src = ((vmask >> it) & 1u) ? inb + (long)(part * stages + s) * plane + goff[it] : zero16;
+                    const int chunk = part * stages + s;
+                    const unsigned char* cb = chunk < XC ? xb + (long)chunk * plane : inb + (long)(chunk - XC) * plane;
+                    const unsigned char* src = ((vmask >> it) & 1u) ? cb + goff[it] : zero16;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
                 }
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         constexpr int TAPS = 9, RING = 3, PF = 2;
         const int S = stages * TAPS;
         const sb8* wfr = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) +
-                         (((long)min(rt, nrt - 1) * C16 + (long)kp * stages) * TAPS * TERMS) * 64 + lane;
+                         (((long)min(rt, nrt - 1) * KC + (long)kp * stages) * TAPS * TERMS) * 64 + lane;
         sb8 af[RING][TERMS];
 #pragma unroll
         for (int q = 0; q < PF; ++q)
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     //      kp * QW .. of its row tile from the KW waves of that row tile -----------------------------------------------------
     float gsum[NT][QW][4];
     const float unscale = TERMS == 2 ? a.acc_scale[0] : 1.f;     // two-term weights are packed times a power of two
-    if (KW > 1 && !a.first) {
+    if (KW > 1 && kchunks > 0) {
         float* red = reinterpret_cast<float*>(lsb);      // [wave][tile][reg][64 lanes]
 #pragma unroll
         for (int t = 0; t < NT; ++t)

@@ -140,7 +140,9 @@ def test_workgroup_order_does_not_change_results_and_info_keys(model_a):
         y0 = torch.stack(m(inp))
     finally:
         m.set_tuning('xcd_remap', 1)
-    assert took == dict(sb_head=1, sb_enc0=1, sb_enc1=1, sb_enc2=1, sb_gx0=1, sb_gx1=1, sb_gx2=1, sb_dec0=1, sb_dec1=1, sb_dec2=1), took
+    # (no batched gate convolution: the recurrent step contracts [x | h] itself, lstm_fuse_x)
+    assert took == dict(sb_head=1, sb_enc0=1, sb_enc1=1, sb_enc2=1, sb_gx0=0, sb_gx1=0, sb_gx2=0, sb_dec0=1, sb_dec1=1, sb_dec2=1), took
+    assert [m.get_info(f'sb_lstm{l}') for l in range(3)] == [1, 1, 1] and m.get_info('lstm_fuse_x') == 1
     assert torch.equal(y0, y1)
     with pytest.raises(Exception):
         m.get_info('sb_enc9')

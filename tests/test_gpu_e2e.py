@@ -516,10 +516,11 @@ def test_one_sequence_split_over_two_ranks_by_direction(tmp_path):
 
 
 def test_round3_kernels_agree_with_the_kernels_they_replace():
-    """The split-bf16 recurrent step (lstm_sb.h), the split-bf16 GEMM phases of the attention block (winblock_sb.h), the q|k|v
-    fusion of the level-2 core (wideblock.h) and the two-stream sweep option: each switched off in turn must give the frames of
-    the default build to fp32 rounding (canonical config, 184x240, T = 6) -- and all of them match the reference's golden frames
-    through the other tests."""
+    """The split-operand recurrent step (lstm_sb.h), the split GEMM phases of the attention block (winblock_sb.h), the q|k|v
+    fusion of the level-2 core (wideblock.h), the two-stream sweep option, the x-part of the gates inside the step, the operand
+    format (two fp16 terms vs three bf16 terms) and the split convolutions altogether: each switched in turn must give the
+    frames of the default build to fp32 rounding (canonical config, 184x240, T = 6) -- and all of them match the reference's
+    golden frames through the other tests."""
     from tests.util import golden_inputs
     from bde2vid_amd import canonical
     from bde2vid_amd.model import build_model
@@ -531,7 +532,8 @@ def test_round3_kernels_agree_with_the_kernels_they_replace():
     with torch.no_grad():
         base = torch.stack(m(inp)).clone()
         assert [m.get_info(f'sb_lstm{l}') for l in range(3)] == [1, 1, 1]
-        for key, off, on in (('lstm_sbk', 0, 1), ('winblock_sb', 0, 1), ('wide_fuse_qkv', 0, 1), ('lstm_two_streams', 1, 0)):
+        for key, off, on in (('lstm_sbk', 0, 1), ('winblock_sb', 0, 1), ('wide_fuse_qkv', 0, 1), ('lstm_two_streams', 1, 0),
+                             ('lstm_fuse_x', 0, 1), ('sb_terms', 3, 2), ('conv_sb', 0, 1)):
             m.set_tuning(key, off)
             try:
                 y = torch.stack(m(inp))
@@ -540,4 +542,5 @@ def test_round3_kernels_agree_with_the_kernels_they_replace():
                 m.set_tuning(key, on)
             assert maxabs(y, base) <= 2e-5, key
             assert torch.equal(y, y2), key
-        assert torch.equal(torch.stack(m(inp)), base)
+        last = torch.stack(m(inp))
+        assert torch.equal(last, base), maxabs(last, base)
