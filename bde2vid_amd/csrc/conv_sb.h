@@ -229,6 +229,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
         const int i = (wave + it * NW) * 64 + lane;
         const int px = i / SLOTS, q = i - px * SLOTS;
         const int r = px / IW, c = px - r * IW;
+        // (stride 2 puts sixteen lanes' 16-byte fragment reads two pixels apart, i.e. into eight bank groups; storing a tile
+        //  row as even columns | odd columns makes them adjacent -- measured: no faster, 157 -> 162 us at level 1; not kept)
         const int iy = iy0 + r, ix = ix0 + c;
         const bool ok = i < nslots && q < SLOTS - 1 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         goff[it] = ok ? (unsigned)((iy * a.Ws + ix) * SB_PIX_BYTES + q * 16) : 0u;
@@ -468,7 +470,14 @@ static int conv_sb_launch_ks(const ConvArgs& a, int G, hipStream_t stream, bool*
     // SB_128x128: four waves of 32 channels x 128 pixels share the pixel fragments through LDS and each stream their own
     // weight fragments (12 KB per tap and workgroup from L2); 2 x 2 waves of 64 x 64 fetch every weight fragment twice
     // (24 KB per tap), which is what saturated the L1 return path.
-    const int shape = conv_sb_pick(KS, STRIDE, a.Cout, a.Win, a.Ho, a.Wo, TERMS);
+    int shape = conv_sb_pick(KS, STRIDE, a.Cout, a.Win, a.Ho, a.Wo, TERMS);
+    if (STRIDE == 1 && shape == SB_128x128 && tuning().conv_nt == 0) {
+        // too few 128-pixel workgroups to give every CU two (a small map, few frames): 64-pixel tiles double them
+        // (decoder 0 at 46 x 60, 16 frames: 275 -> 239 us; the stride-2 encoder of level 2 lost: 169 -> 200 us, kept at 128)
+        const int groups = a.decide_groups ? a.decide_groups : G;
+        const long wgs = (long)cdiv(a.Ho * a.Wo, 128) * cdiv(a.Cout, 128) * groups * a.N;
+        if (wgs < 2 * 256 && conv_sb_tile_mode(KS, STRIDE, 64, a.Win, a.Ho, a.Wo, TERMS) >= 0) shape = SB_128x64;
+    }
     if (shape == SB_128x128) {
         if (tuning().conv_nt == 2) return conv_sb_launch_shape<KS, STRIDE, 2, 2, 2, 2, TERMS>(a, G, stream, launched);
         return conv_sb_launch_shape<KS, STRIDE, 1, 4, 4, 1, TERMS>(a, G, stream, launched);

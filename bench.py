@@ -25,7 +25,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak (= fp32 vector peak)
-SPLIT_BF16_PEAK_TFLOPS = 2500.0 / 6   # fp32-equivalent work on the bf16 matrix cores: dense bf16 peak / six MFMAs per fp32 block (csrc/conv_sb.h)
+# fp32-equivalent work on the 16-bit matrix cores (csrc/split.h): dense bf16 / fp16 peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
+# divided by the MFMAs per fp32 block of the operand format -- three for two fp16 terms (the default), six for three bf16 terms
+SPLIT_PEAK_TFLOPS = {2: 2500.0 / 3, 3: 2500.0 / 6}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
 ATOMIC_PEAK_GBPS = 1300.0       # MI355X_MICROARCH.md, global float atomics: ~1.3 TB/s of added bytes chip-wide
 PROFILE_TAG = 'r3'              # the committed rocprofv3 artefacts this line cites: profiles/<tag>_*
@@ -74,8 +76,9 @@ def host_cores():
 class Work:
     """flops / bytes per launch of each profiled span of one forward (config, T, B, Hp, Wp)."""
 
-    def __init__(self, cfg, T, B, H, W):
+    def __init__(self, cfg, T, B, H, W, fuse_x=()):
         self.cfg, self.T, self.B, self.H, self.W = cfg, T, B, H, W
+        self.fuse_x = set(fuse_x)          # levels whose recurrent step contracts [x | h] itself (no batched gate convolution)
 
     def _lvl(self, l):
         return self.cfg.enc_in(l), self.cfg.enc_out(l), (self.H >> (l + 1)) * (self.W >> (l + 1))
@@ -111,7 +114,8 @@ class Work:
             return 2 * TB * hw * 2.0 * 4 * cout * cout * 9, 'mfma'
         if base == 'lstm':
             cin, cout, hw = self._lvl(idx)
-            return 2 * B * hw * (2.0 * 4 * cout * cout * 9 + 20.0 * cout), 'mfma'
+            k = 2 * cout if idx in self.fuse_x else cout
+            return 2 * B * hw * (2.0 * 4 * cout * k * 9 + 20.0 * cout), 'mfma'
         if base in ('winblock', 'wideblock'):
             return self.attn_block_flops(idx), 'mfma'
         if base == 'dec_conv':
@@ -141,9 +145,9 @@ class Work:
         return None
 
     def first_step_flops(self, l):
-        """The first step of a sweep starts from h = 0 and skips the contraction: pointwise flops only."""
+        """The first step of a sweep starts from h = 0 and skips the h-part of the contraction."""
         cin, cout, hw = self._lvl(l)
-        return 2 * self.B * hw * 20.0 * cout
+        return 2 * self.B * hw * ((2.0 * 4 * cout * cout * 9 if l in self.fuse_x else 0.0) + 20.0 * cout)
 
     def stage_flops(self):
         """Per FORWARD: encoder (north star: encoder convs + gate convs + recurrent steps), attention levels, decoder, head."""
@@ -163,13 +167,13 @@ class Work:
 
 KERNEL_OF_SPAN = [
     # span name pattern -> (regex on the rocprofv3 kernel name, readable description)
-    (r'lstm(\d)', r'lstm_sb_step_kernel|lstm16_step_kernel', 'recurrent ConvLSTM step of level {0}, both directions, pointwise tail fused (csrc/lstm_sb.h: split bf16; csrc/lstm16.h where no shape fits)'),
-    (r'winblock(\d)', r'winblock_kernel', 'one temporal window-attention block of level {0} per launch (csrc/winblock.h)'),
+    (r'lstm(\d)', r'lstm_sb_step_kernel|lstm16_step_kernel', 'recurrent ConvLSTM step of level {0}, both directions, gates of [x | h] contracted on split operands, pointwise tail fused (csrc/lstm_sb.h; csrc/lstm16.h where no shape fits)'),
+    (r'winblock(\d)', r'winblock_sb_kernel|winblock_kernel', 'one temporal window-attention block of level {0} per launch (csrc/winblock_sb.h: GEMM phases on split operands, attention phase fp32)'),
     (r'wideblock(\d)', r'wideblock_', 'temporal window-attention block of level {0} (csrc/wideblock.h)'),
     (r'gates_x(\d)', r'conv_sb_kernel<3, 1|conv_vec_kernel<3, 1', 'x-part of the ConvLSTM gates of level {0}, 3x3 conv batched over T, both directions (csrc/conv_sb.h; conv_vec.h when no split-bf16 shape fits)'),
     (r'enc_conv(\d)', r'conv_sb_kernel<5, 2|conv_vec_kernel<5, 2', 'encoder 5x5 stride-2 conv of level {0}, batched over T, both directions (csrc/conv_sb.h / conv_vec.h)'),
     (r'dec_conv(\d)', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_sb.h / conv_vec.h)'),
-    (r'head', r'conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_vec.h)'),
+    (r'head', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_sb.h / conv_vec.h)'),
     (r'chain_(\w+?)(\d)', r'pw_gemm_kernel|attn_mfma16_kernel|attn_core_kernel|token_fused_kernel', 'split attention path of level {1}: {0}'),
     (r'wide_core(\d)', r'attn_tok16_kernel', 'window-attention core of level {0}, one workgroup per (window, head) (csrc/wideblock.h)'),
     (r'wide_(\w+?)(\d)', r'tokgemm_kernel', 'token GEMM of the level-{1} attention chain: {0} (csrc/wideblock.h)'),
@@ -456,7 +460,11 @@ def main():
             t_, c_ = C.c_double(), C.c_int64()
             L.bde_profile_get(model._h, nm.encode(), C.byref(t_), C.byref(c_))
             spans[nm] = (t_.value, int(c_.value))
-        work = Work(cfg, T, B, H, W)
+        terms = model.get_info('sb_terms')
+        fuse_x = [l for l in range(cfg.num_encoders)
+                  if model.get_info('lstm_fuse_x') == 1 and model.get_info(f'sb_lstm{l}') == 1 and model.get_info(f'sb_gx{l}') == 0
+                  and spans.get(f'gates_x{l}', (0, 0))[1] == 0]
+        work = Work(cfg, T, B, H, W, fuse_x)
         kernels = {}
         for nm, (ms, cnt) in spans.items():
             fb = work.flops(nm)
@@ -476,10 +484,12 @@ def main():
         for nm, k in kernels.items():
             k['share'] = k['ms_per_forward'] / fwd_ms if fwd_ms > 0 else None
             mm = re.fullmatch(r'(gates_x|enc_conv|dec_conv|lstm)(\d)', nm)
-            split = bool(mm) and model.get_info(sb_key[mm.group(1)] + mm.group(2)) == 1     # what the library launched
-            k['peak'] = SPLIT_BF16_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            split = (bool(mm) and model.get_info(sb_key[mm.group(1)] + mm.group(2)) == 1) or \
+                    (nm == 'head' and model.get_info('sb_head') == 1)                        # what the library launched
+            k['peak'] = SPLIT_PEAK_TFLOPS[terms] if split else FP32_MFMA_PEAK_TFLOPS
             if split:
-                k['bound'] = 'mfma (bf16 matrix cores, 6 MFMAs per fp32 block)'
+                k['bound'] = ('mfma (fp16 matrix cores, two-term split operands: 3 MFMAs per fp32 block)' if terms == 2 else
+                              'mfma (bf16 matrix cores, three-term split operands: 6 MFMAs per fp32 block)')
             k['frac'] = k['achieved'] / k['peak']
         dom = max(kernels, key=lambda n: kernels[n]['ms_per_forward'])
         dk = kernels[dom]
@@ -506,7 +516,10 @@ def main():
             'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (bf16x3 split MFMA where conv_sb / winblock apply, f32 accumulate)', 'data': 'synthetic',
+            'dtype': ('f32 (operands split into two fp16 terms on the matrix cores where conv_sb / lstm_sb / winblock_sb apply: '
+                      '3 MFMAs per fp32 block, f32 accumulate)' if terms == 2 else
+                      'f32 (operands split into three bf16 terms on the matrix cores where conv_sb / lstm_sb / winblock_sb apply: '
+                      '6 MFMAs per fp32 block, f32 accumulate)'), 'data': 'synthetic',
             'single_stream': {'value': args.steps * T * B * world / single_elapsed, 'unit': 'frames/s',
                               'ms_per_step': 1e3 * single_elapsed / args.steps, 'graph_replay': bool(single_graph),
                               'what': f'the same {args.steps} steps with ONE sequence in flight per GPU (pipeline 1): per-sequence '
@@ -534,8 +547,10 @@ def main():
                          'flops_per_launch': dk['flops_per_launch'], 'share_of_forward': dk['share'],
                          'chosen': 'the kernel with the largest total time among the HIP-event spans of this run',
                          'stages': stages,
-                         'stages_note': 'fp32-equivalent flops / time against the fp32 matrix peak (157.3); the convolutions whose '
-                                        'kernels[*].peak is 416.7 ran as split bf16 on the bf16 matrix cores (dense bf16 peak / 6)',
+                         'stages_note': 'fp32-equivalent flops / time against the fp32 matrix peak (157.3); the spans whose '
+                                        f'kernels[*].peak is {SPLIT_PEAK_TFLOPS[terms]:.1f} ran on split operands on the 16-bit matrix '
+                                        f'cores (dense peak 2500 / {3 if terms == 2 else 6} MFMAs per fp32 block, csrc/split.h); '
+                                        f'recurrent steps of levels {fuse_x} contract [x | h] (no gates_x launch)',
                          'kernels': {nm: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()}
                                      for nm, kk in sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_forward'])},
                          'eager_forward_ms': fwd_ms,

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""VGPR/AGPR/occupancy/scratch per kernel of the two translation units (hipcc -Rpass-analysis=kernel-resource-usage).
+"""VGPR/AGPR/occupancy/scratch per kernel of the three translation units (hipcc -Rpass-analysis=kernel-resource-usage).
 usage: tools/kernel_resources.py [name filter]"""
 import re, subprocess, sys, os
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = ''
-for tu in ('bde_api.hip', 'conv_tu.hip'):
+for tu in ('bde_api.hip', 'conv_tu.hip', 'sb_tu.hip'):
     out += subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DBDE_BUILD', '--cuda-device-only', '-c',
                            '-Rpass-analysis=kernel-resource-usage', '-o', '/tmp/_kr.o',
                            os.path.join(repo, 'bde2vid_amd/csrc', tu)], capture_output=True, text=True).stderr
