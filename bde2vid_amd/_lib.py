@@ -50,6 +50,7 @@ SIGNATURES = {
     'bde_get_info': (_I, [_P, C.c_char_p, C.POINTER(_L)]),
     'bde_debug_occupancy': (_I, [C.c_char_p]),
     'bde_debug_conv_shape': (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int32)]),
+    'bde_debug_split': (C.c_float, [C.POINTER(C.c_float), C.c_int64, _I, C.c_float, C.POINTER(C.c_uint16)]),
     'bde_debug_token_stamps': (_I, [_P, C.POINTER(_L), _I]),
     'bde_profile_reset': (_I, [_P, _I]),
     'bde_profile_names': (_I, [_P, C.c_char_p, _L]),

@@ -2859,6 +2859,16 @@ int bde_debug_conv_shape(int32_t ks, int32_t stride, int32_t cout, int32_t in_h,
     return shape;
 }
 
+float bde_debug_split(const float* x, int64_t n, int32_t terms, float scale, uint16_t* out) {
+    if (!x || !out || n <= 0 || (terms != 2 && terms != 3)) return 0.f;
+    for (int64_t i = 0; i < n; ++i) {
+        unsigned short t[3];
+        split_terms(x[i], terms, scale, t);
+        for (int k = 0; k < terms; ++k) out[i * terms + k] = t[k];
+    }
+    return terms == 2 ? sb_weight_scale(x, (long)n) : 1.f;
+}
+
 int bde_debug_occupancy(const char* kernel) {
     int nb = -1;
     std::string k(kernel ? kernel : "");

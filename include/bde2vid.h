@@ -156,6 +156,10 @@ int bde_debug_occupancy(const char* kernel);
  * channels x 128 pixels, 2 = 128 x 64, 3 = 64 x 128, 4 = 32 x 256 on 2-D pixel tiles, 5 = 64 x 128 on 2-D pixel tiles;
  * *row_tiles (may be NULL) = pixel tiles per image row, 0 = tiles run linearly over rows, < 0 = minus the columns of a 2-D tile. */
 int bde_debug_conv_shape(int32_t ks, int32_t stride, int32_t cout, int32_t in_h, int32_t in_w, int32_t* row_tiles);
+/* Diagnostics (host arithmetic, no GPU): the split operand formats of csrc/split.h as the weight packer applies them.
+ * terms = 2: out[2 i], out[2 i + 1] = the two fp16 terms (bit patterns) of x[i] * scale; terms = 3: out[3 i ..] = the three bf16
+ * terms of x[i] (scale ignored).  Returns the power-of-two packing scale split.h would choose for x[0..n) (terms = 2; else 1). */
+float bde_debug_split(const float* x, int64_t n, int32_t terms, float scale, uint16_t* out);
 /* Diagnostics: s_memtime stamps of the fused token kernel's phases ([block<64][wave][8]); first call
  * with host_out == NULL enables them, a later call copies n values back. */
 int bde_debug_token_stamps(bde_model* m, int64_t* host_out, int32_t n);

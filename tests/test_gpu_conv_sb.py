@@ -219,3 +219,44 @@ def test_non_finite_activations_same_class_on_both_arithmetic_paths(model_a):
         assert maxabs(y[fin], ref[fin]) <= 1e-4 * float(ref[fin].abs().max())
     assert torch.equal(torch.isnan(outs[0][0]), torch.isnan(ref[0]))        # NaN in, NaN out: identical on the fp32 path
     assert torch.equal(torch.isnan(outs[1][0]), torch.isnan(ref[0]))        # ... and on the split path
+
+
+def test_range_of_the_two_term_format(model_a):
+    """fp16 terms keep 5 exponent bits (csrc/split.h): an activation of 65520 or more turns infinite in the default two-term
+    format -- the output is non-finite on that activation's footprint, never a wrong finite number -- while three bf16 terms
+    (set_tuning('sb_terms', 3)) and the fp32 kernels carry it; just below the limit all three agree with torch.  Tiny
+    activations (fp16 subnormal range) keep an absolute accuracy of 2^-25."""
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    level, C, N, H, W = 2, cfg.enc_out(2), 16, 23, 30
+    base = torch.from_numpy(dense_like((2, N, C, H, W), 991))
+
+    def run(x, terms):
+        m.set_tuning('sb_terms', terms)
+        try:
+            return ops.gate_conv(m, level, x.cuda()).cpu()
+        finally:
+            m.set_tuning('sb_terms', 2)
+
+    def ref_of(x):
+        out = []
+        for d, name in enumerate(('forward_encoder', 'backward_encoder')):
+            w = sd[f'{O.P}{name}.{level}.recurrent_block.Gates.weight'][:, :C].double()
+            out.append(F.conv2d(x[d].double(), w, sd[f'{O.P}{name}.{level}.recurrent_block.Gates.bias'].double(), padding=1))
+        return torch.stack(out)
+
+    big = base.clone()
+    big[0, 4, 33, 10, 12] = 1.0e5                       # beyond fp16
+    big[1, 7, 60, 3, 3] = 65000.0                       # within
+    ref = ref_of(big)
+    y2, y3 = run(big, 2), run(big, 3)
+    scale = float(ref.abs().max())
+    assert torch.isfinite(y3).all() and maxabs(y3.double(), ref) <= 2e-6 * scale
+    bad = ~torch.isfinite(y2)
+    assert bad[0, 4, :, 9:12, 11:14].all() and int(bad.sum()) == 9 * 4 * C          # exactly the 3x3 footprint, every gate row
+    assert maxabs(y2[~bad].double(), ref[~bad]) <= 2e-6 * scale                       # 65000 is carried
+    tiny = base * 1e-6                                   # every low term (and many leading ones) subnormal in fp16
+    ref = ref_of(tiny)
+    y2 = run(tiny, 2)
+    assert maxabs(y2.double(), ref) <= 1e-5 * float((ref - ref.mean()).abs().max()) + 2e-7

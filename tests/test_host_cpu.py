@@ -249,10 +249,10 @@ def test_split_bf16_conv_shapes_at_the_baseline_resolutions():
         return L.bde_debug_conv_shape(ks, stride, cout, h, w, C.byref(rt)), rt.value
 
     expect = {
-        (184, 240): dict(enc=[(5, -1), (2, 1), (1, 0)], gx=[(1, 1), (1, 0), (1, 0)], dec=[(1, 0), (3, 1), (4, 2)]),
-        (264, 352): dict(enc=[(5, -1), (1, 1), (2, 0)], gx=[(1, 0), (1, 0), (1, 0)], dec=[(1, 0), (3, 2), (4, 3)]),
-        (480, 640): dict(enc=[(5, -1), (2, 3), (1, 1)], gx=[(2, 5), (1, 0), (1, 0)], dec=[(1, 0), (3, 3), (4, 5)]),
-        (720, 1280): dict(enc=[(5, -1), (2, 5), (2, 3)], gx=[(1, 5), (2, 5), (1, 0)], dec=[(2, 5), (3, 5), (4, 10)]),
+        (184, 240): dict(enc=[(5, -8), (2, 1), (1, 0)], gx=[(1, 1), (1, 0), (1, 0)], dec=[(1, 0), (3, 1), (4, -16)]),
+        (264, 352): dict(enc=[(5, -16), (1, 1), (2, 0)], gx=[(1, 0), (1, 0), (1, 0)], dec=[(1, 0), (3, 2), (4, -16)]),
+        (480, 640): dict(enc=[(5, -16), (2, 3), (1, 1)], gx=[(2, 5), (1, 0), (1, 0)], dec=[(1, 0), (3, 3), (4, -16)]),
+        (720, 1280): dict(enc=[(5, -16), (2, 5), (2, 3)], gx=[(1, 5), (2, 5), (1, 0)], dec=[(2, 5), (3, 5), (4, -16)]),
     }
     chans = (64, 128, 256)
     for (H, W), e in expect.items():
@@ -265,3 +265,55 @@ def test_split_bf16_conv_shapes_at_the_baseline_resolutions():
             assert shape(5, 1, cout, (H >> (l + 1)) * 2, (W >> (l + 1)) * 2) == e['dec'][j], ('dec', H, W, j)
     # not a convolution the split-bf16 kernels are built for
     assert shape(7, 1, 128, 64, 64)[0] == 0 and shape(3, 2, 128, 64, 64)[0] == 0
+
+
+def test_split_operand_formats_host_arithmetic():
+    """csrc/split.h as the weight packer applies it (bde_debug_split, no GPU): the two-term fp16 split is numpy's float16
+    arithmetic bit for bit (round to nearest even, subnormals kept, |x| >= 65520 -> Inf in the leading term alone); it carries
+    x to max(2^-23 |x|, 2^-25); the three-term bf16 split is exact for every fp32 value whose low term does not underflow;
+    the packing scale puts the largest magnitude into [2^14, 2^15)."""
+    import ctypes as C
+    from bde2vid_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4000).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 4, 4000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e5, -1e6, 6.1e-5, 5.9e-8, 2.9e-8, 1e-9,
+                                  np.inf, -np.inf, np.nan, 0.1, 0.3333333], dtype=np.float32)]).astype(np.float32)
+    n = x.size
+
+    def split(terms, scale=1.0):
+        out = np.zeros(n * terms, dtype=np.uint16)
+        sc = L.bde_debug_split(x.ctypes.data_as(C.POINTER(C.c_float)), n, terms, C.c_float(scale), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+        return out.reshape(n, terms), sc
+
+    t2, _ = split(2)
+    with np.errstate(over='ignore', invalid='ignore'):
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+    special = ~np.isfinite(hi.astype(np.float32))
+    lo = np.where(special, np.float16(0), lo)
+    assert np.array_equal(t2[:, 0], hi.view(np.uint16)), 'leading fp16 term'
+    fin = ~special
+    assert np.array_equal(t2[fin, 1], lo.view(np.uint16)[fin]), 'second fp16 term'
+    assert np.all(t2[special, 1] == 0)                                   # Inf / NaN / out of range ride in the leading term alone
+    rec = t2[:, 0].view(np.float16).astype(np.float64) + t2[:, 1].view(np.float16).astype(np.float64)
+    err = np.abs(rec[fin] - x[fin].astype(np.float64))
+    assert np.all(err <= np.maximum(2.0 ** -23 * np.abs(x[fin]), 2.0 ** -25)), float(err.max())
+    assert np.isinf(rec[x == np.float32(65520.0)]).all() and np.isfinite(rec[x == np.float32(65504.0)]).all()
+
+    t3, one = split(3)
+    assert one == 1.0
+    f3 = (t3.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    ok = np.isfinite(x) & (np.abs(x) >= 2.0 ** -100)
+    assert np.array_equal(f3[ok].sum(axis=1), x[ok].astype(np.float64)), 'three bf16 terms are exact'
+
+    # the packing scale: a power of two, max |w| * scale in [2^14, 2^15); small weights keep 22 bits once scaled
+    w = (rng.standard_normal(2000) * 0.02).astype(np.float32)
+    out = np.zeros(2 * w.size, dtype=np.uint16)
+    sc = L.bde_debug_split(w.ctypes.data_as(C.POINTER(C.c_float)), w.size, 2, C.c_float(1.0), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    assert sc > 0 and np.log2(sc) == np.round(np.log2(sc)) and 2.0 ** 14 <= np.abs(w).max() * sc < 2.0 ** 15
+    L.bde_debug_split(w.ctypes.data_as(C.POINTER(C.c_float)), w.size, 2, C.c_float(sc), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    o = out.reshape(-1, 2)
+    rec = (o[:, 0].view(np.float16).astype(np.float64) + o[:, 1].view(np.float16).astype(np.float64)) / sc
+    big = np.abs(w) >= np.abs(w).max() * 2.0 ** -17
+    assert np.all(np.abs(rec[big] - w[big]) <= 2.0 ** -22 * np.abs(w[big]))
