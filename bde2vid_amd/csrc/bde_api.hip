@@ -1349,7 +1349,6 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         const long C = m->cout(l), hw = (long)(H >> (l + 1)) * (W >> (l + 1));
         const long hwp = cdivl(hw, 16) * 16;              // token tiles of 16 (wideblock.h)
         BDE_TRY(ws_alloc(ws, &ws.xenc[l], 2 * TB * C * hw));
-        BDE_TRY(ws_alloc(ws, &ws.gx[l], 2 * TB * 4 * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.hseq[l], 2 * TB * C * hw));
         BDE_TRY(ws_alloc(ws, &ws.cst[l], 2 * (long)B * C * hw));
         if (gru) {
@@ -1360,6 +1359,9 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         }
         if (!gru && c.use_rc && lstm_sbk_ok(m, l, H >> (l + 1), W >> (l + 1)))
             BDE_TRY(ws_alloc(ws, &ws.hsk[l], 2 * split_bf16_bytes(2L * B, (int)C, hw) / 4 + 4));
+        // x-part of the gates of all frames, both directions -- the largest buffer of a level (20 GB at 480 x 640, T = 32, B = 4);
+        // not needed where the recurrent step contracts [x | h] itself (lstm_fuse_x)
+        if (!lstm_sbx_ok(m, l, H >> (l + 1), W >> (l + 1))) BDE_TRY(ws_alloc(ws, &ws.gx[l], 2 * TB * 4 * C * hw));
         if (!gru && c.use_rc && lstm_sb_ok(m, l, B, H >> (l + 1), W >> (l + 1))) {
             BDE_TRY(ws_alloc(ws, &ws.hsb[l], 2 * split_bf16_bytes(2L * B, (int)C, hw) / 4 + 4));
             BDE_TRY(ws_alloc(ws, &ws.ghb[l], 2L * B * 4 * C * hw));
@@ -1484,6 +1486,7 @@ static int run_enc_gx(bde_model* m, int l, const float* in, int f0, int nf, int 
     m->enc[l].sb_used = enc_v.sb_used;                                   // (the launch ran on a copy / one-direction view of the layer)
     if (step_x) { m->gx[l].sb_used = 0; return BDE_OK; }
     // gx = conv3x3(x; W[:, :C]) + bias   (submodules.py:316-317, x half of the stacked input)
+    BDE_REQUIRE(ws.gx[l] != nullptr, "gate convolution: no x-part buffer at level %d", l);
     ConvCall gxc;
     gxc.pl = &gx_v;
     gxc.in = ws.xenc[l] + (long)f0 * C * hw + (one_dir ? dsel * TB * C * hw : 0);
@@ -1561,10 +1564,12 @@ static int run_recurrent_steps_sbk(bde_model* m, int l, int T, int B, int h, int
         a.acc_scale = m->P(pl.sh_unscale_off);
         a.wpk = reinterpret_cast<const unsigned short*>(m->P(pl.split_off(terms)));
         a.w_gs = pl.split_sz(terms) * 2;
-        a.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
-        a.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - a.gx;
-        a.gx_ns = (long)4 * C * hw;
-        if (step_x) {
+        if (!step_x) {
+            BDE_REQUIRE(ws.gx[l] != nullptr, "recurrent step: no x-part buffer at level %d", l);
+            a.gx = ws.gx[l] + (long)tf * B * 4 * C * hw;
+            a.gx_gs = (ws.gx[l] + TB * 4 * C * hw + (long)tb * B * 4 * C * hw) - a.gx;
+            a.gx_ns = (long)4 * C * hw;
+        } else {
             // x_t of both directions in ws.sb2 (run_enc_gx): [direction][TB frames], forward reads frame tf, backward frame tb
             const unsigned char* xs = reinterpret_cast<const unsigned char*>(ws.sb2);
             a.xin = xs + (long)tf * B * sb_ns;
@@ -2765,7 +2770,12 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_two_streams") { m->lstm_two_streams = (int)value; return BDE_OK; }
-    if (std::string(key) == "lstm_fuse_x") { m->lstm_fuse_x = (int)value; return BDE_OK; }
+    if (std::string(key) == "lstm_fuse_x") {
+        if (m->lstm_fuse_x != (int)value)
+            for (auto& w : m->wslots) w.release();           // the x-part buffer exists only without it
+        m->lstm_fuse_x = (int)value;
+        return BDE_OK;
+    }
     if (std::string(key) == "lstm_sbk") {
         if (m->use_lstm_sbk != (int)value)
             for (auto& w : m->wslots) w.release();
