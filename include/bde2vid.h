@@ -124,15 +124,20 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *              call of a shape; 0 launches eagerly.
  *   "fused_min_tiles": a level with at least this many 32-pixel tiles runs the post-softmax part of an
  *                      attention block as one fused kernel instead of three GEMM launches (default 160).
- *   "conv_sb": 1 (default) runs the batched convolutions that have a split-bf16 shape (csrc/conv_sb.h) on the bf16
- *              matrix cores with three-term split operands (fp32-equivalent); 0 keeps every convolution on the fp32 kernels.
+ *   "sb_terms": operand format of every split kernel (csrc/split.h): 2 (default) = two fp16 terms, three MFMAs per fp32
+ *              block, fp32-equivalent accuracy, finite activations must stay below 65520 (beyond it they turn infinite and the
+ *              frames non-finite, never wrong); 3 = three bf16 terms, six MFMAs, fp32's exponent range.
+ *   "conv_sb": 1 (default) runs the batched convolutions that have a split-operand shape (csrc/conv_sb.h) on the 16-bit
+ *              matrix cores (fp32-equivalent); 0 keeps every convolution -- and the recurrent step -- on the fp32 kernels.
  *   "xcd_remap": 1 (default) orders the workgroups of the batched convolutions so that each XCD's L2 sees one contiguous
  *              range of (frame, pixel tile, channel group); 0 = plain grid order.  Same results.
  *   "fuse_enc_sb": 1 (default) lets an encoder convolution store its result only as the split-bf16 image its gate
  *              convolution reads; 0 writes fp32 planes and converts them in a pass of their own (same frames, bit for bit).
- *   "lstm_sbk": 1 (default) runs the recurrent ConvLSTM step on the bf16 matrix cores with three-term split operands and the
+ *   "lstm_sbk": 1 (default) runs the recurrent ConvLSTM step on the 16-bit matrix cores with split operands and the
  *              pointwise tail fused (csrc/lstm_sb.h: fp32-equivalent) wherever a shape fits; 0 = the fp32 matrix-core step (lstm16.h).
- *   "winblock_sb": 1 (default) runs the four GEMM phases of that one-launch block on the bf16 matrix cores, three-term split
+ *   "lstm_fuse_x": 1 (default) lets that step contract the stacked input [x | h] itself (submodules.py:316-317): no batched
+ *              gate convolution and no buffer for its result; 0 = the x-part of the gates batched over T by conv_sb.
+ *   "winblock_sb": 1 (default) runs the four GEMM phases of that one-launch block on the 16-bit matrix cores, split
  *              operands (csrc/winblock_sb.h: fp32-equivalent); 0 = fp32 MFMAs throughout (winblock.h).
  *   "winblock": 1 (default) runs an attention block of a 64-channel / 16-head level as ONE launch
  *               (csrc/winblock.h); 0 keeps the split path (attention core + fused token kernel).
@@ -143,9 +148,10 @@ int bde_wait_outputs(bde_model* m, void* stream);
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 /* Read back the state the measurement has to be honest about: "debug_skip" (non-zero = stages skipped, results
  * invalid), "graph" (0 also after a failed capture), "graphs_live" (workspaces replaying a captured launch
- * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "lstm_sb", "lstm_sbk", "last_stream", "device", "packed_numel"; and which
- * convolutions the latest forward ran as split bf16 (csrc/conv_sb.h): "sb_enc<l>", "sb_gx<l>", "sb_dec<j>" (0 / 1), and
- * "sb_lstm<l>": the recurrent steps of level l ran on the fused split-bf16 step kernel (csrc/lstm_sb.h).
+ * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "sb_terms", "lstm_sb", "lstm_sbk", "lstm_fuse_x", "last_stream",
+ * "device", "packed_numel"; and which convolutions the latest forward ran on split operands (csrc/conv_sb.h): "sb_head",
+ * "sb_enc<l>", "sb_gx<l>" (0 when the step contracts [x | h] itself: no such launch), "sb_dec<j>" (0 / 1), and
+ * "sb_lstm<l>": the recurrent steps of level l ran on the fused split-operand step kernel (csrc/lstm_sb.h).
  * Settings are per model object. */
 int bde_get_info(const bde_model* m, const char* key, int64_t* value);
 
