@@ -1,20 +1,23 @@
-// Recurrent ConvLSTM step with fp32-equivalent arithmetic on the bf16 matrix cores (conv_sb.h's three-term split, six
-// v_mfma_f32_32x32x16_bf16 per fp32 block) AND the pointwise tail in the epilogue -- the kernel on the sequential critical path
-// of every level (V5.py:122-135; ConvLSTM.forward, submodules.py:293-334).
+// Recurrent ConvLSTM step with fp32-equivalent arithmetic on the 16-bit matrix cores (split operands, split.h: two fp16 terms /
+// three MFMAs per fp32 block by default, three bf16 terms / six MFMAs as TERMS = 3) AND the pointwise tail in the epilogue -- the
+// kernel on the sequential critical path of every level (V5.py:122-135; ConvLSTM.forward, submodules.py:293-334).
 //
-//   gates[4][Ch] = conv3x3(h_prev; W[:, C:]) + gx  (gx = x-part incl. bias, batched over T by conv_sb.h);
+//   gates[4][Ch] = conv3x3([x_t | h_prev]; W) + b                         (the reference's stacked input, :316-317)
 //   i, f, o = sigmoid, g = tanh;  c = f c + i g;  h = o tanh(c)            (chunk order i, f, o, g, :320-332)
 //
-// lstm16.h runs this step on the fp32 matrix cores: 6.5 GFLOP per step at 64 FLOP/clk/SIMD is 100 k cycles when perfectly
-// balanced (46-50 us); it measures 67 us.  On the bf16 cores the same contraction is 37 k cycles of MFMA per SIMD; what decides
-// the step then is (a) every SIMD getting the same number of MFMAs, (b) the weights -- 28 MB of split terms at level 2 -- crossing
-// the L2 -> CU path few times, (c) no second launch for the pointwise half.  A level's step is therefore cut to ONE work shape,
-//   a wave = 32 gate rows x (NT x 32) pixels x a quarter .. all of K,        432 (NT = 2) or 648 (NT = 3) MFMAs,
+// K runs over the 16-channel chunks of x_t (its SB16 image, written by the level's encoder convolution) and then those of h_prev
+// (xchunks > 0); with xchunks = 0 the x-part arrives precomputed as gx (batched over T by conv_sb.h) and K is h_prev alone.
+//
+// lstm16.h runs the h-part on the fp32 matrix cores: 6.5 GFLOP per step at 64 FLOP/clk/SIMD is 100 k cycles when perfectly
+// balanced (46-50 us); it measures 67 us.  What decides the step on the 16-bit cores is (a) every SIMD getting the same number of
+// MFMAs, (b) the weights crossing the L2 -> CU path few times, (c) no second launch for the pointwise half.  A level's step is
+// therefore cut to ONE work shape,
+//   a wave = 32 gate rows x (NT x 32) pixels x a quarter .. all of K,
 // by choosing, per level, how the four waves of a workgroup divide rows and K:
 //   RTW x KW = 4:  RTW row tiles of 32 (weights differ per wave) x KW parts of K (waves of a row tile split the channel chunks
 //   and are summed through LDS).  Config A, 184 x 240:  level 0: 4 x 1, NT 2 (692 workgroups, 3 per CU);  level 1: 2 x 2, NT 2
-//   (704, 3 per CU);  level 2: 1 x 4, NT 3 = three image rows (512, 2 per CU): 1296 MFMAs per SIMD at every level, each weight
-//   fragment used for 64-96 pixels, weights read 226-311 MB per step from L2.
+//   (704, 3 per CU);  level 2: 1 x 4, NT 3 = three image rows (512, 2 per CU): 1296 MFMAs per SIMD at every level with two-term
+//   operands and K = [x | h], each weight fragment used for 64-96 pixels.
 //
 // Rows are packed GATE-INTERLEAVED: row 8 q + 4 hl + gate of a 32-row tile = that gate of hidden channel 8 tile + 4 hl + q, so the
 // four gates of a (channel, pixel) are four consecutive accumulator registers of one lane (acc_row: rows 8 (r >> 2) + 4 (lane >> 5)
@@ -22,8 +25,8 @@
 // c / h are finished in registers.  h leaves as fp32 planes (the level's output sequence) and as the SB16 image the next
 // step's convolution reads, assembled through LDS into 16-byte pieces.
 //
-// Operands as in conv_sb.h: h_prev SB16 [B][C/16][H][W][3 terms][16 ch] bf16, halo tiles staged by LDS-DMA at a 112-byte pixel
-// pitch (one tile per K part and stage); weights [row tile][chunk][tap][term][64 lanes][8] L2 -> registers, two taps ahead.
+// Operands as in conv_sb.h: SB16 [B][C/16][H][W][TERMS][16 ch], halo tiles staged by LDS-DMA at a pixel pitch of 32 TERMS + 16
+// bytes (one tile per K part and stage); weights [row tile][chunk][tap][term][64 lanes][8] L2 -> registers, two taps ahead.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv_sb.h"

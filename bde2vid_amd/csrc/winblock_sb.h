@@ -1,19 +1,19 @@
 // winblock_kernel (winblock.h) with its four GEMM phases -- q|k|v, proj, fc1, fc2: 1.53 of the block's 2.0 GFLOP and half of
-// its cycles on v_mfma_f32_16x16x4_f32 -- moved to the bf16 matrix cores with three-term split operands (conv_sb.h's
-// arithmetic: a b ~= a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1, fp32 accumulate, fp32-equivalent accuracy):
-// per 16 x 16 output tile and K = 64, 12 v_mfma_f32_16x16x32_bf16 (16 cycles each) instead of 16 fp32 MFMAs (32 cycles each).
+// its cycles on v_mfma_f32_16x16x4_f32 -- moved to the 16-bit matrix cores with split operands (split.h: fp32 accumulate,
+// fp32-equivalent accuracy): per 16 x 16 output tile and K = 64, six v_mfma_f32_16x16x32_f16 with two fp16 terms (TERMS = 2, the
+// default) or twelve ..._bf16 with three bf16 terms (16 cycles each) instead of 16 fp32 MFMAs (32 cycles each).
 // Scores, softmax and p*v are winblock.h's, unchanged (K = head_dim = 4 is the fp32 16x16x4 MFMA's own shape).
 //
 // What changes around the GEMMs:
-//   * weights: split at pack time into A-fragment order of the 16x16x32 MFMA, [row tile 16][k-step 32][term 3][64 lanes][8]
+//   * weights: split at pack time into A-fragment order of the 16x16x32 MFMA, [row tile 16][k-step 32][term][64 lanes][8]
 //     (lane l = W[16 tile + (l & 15)][32 kstep + 8 (l >> 4) + j]), 16-byte loads L2 -> registers, a phase ahead;
-//   * activations: every GEMM's token operand lives in LDS as three bf16 images in B-fragment order
+//   * activations: every GEMM's token operand lives in LDS as TERMS 16-bit images in B-fragment order
 //     [term][token tile 16][chunk of 8 channels][16 tokens][8 channels]: a lane's fragment is one ds_read_b128, the 16
 //     lanes of a read group hit 16 different bank groups.  The gather splits the window's tokens once as they arrive
-//     (v_cvt_pk_bf16_f32: 5.5 vector instructions per element), the attention phase writes its output already split,
+//     (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: 3 / 5.5 vector instructions per element), the attention phase writes its output already split,
 //     the proj / fc1 epilogues split x1 / the hidden activations for the GEMM that follows;
-//   * LDS: the split tokens (60 KB for 10 token tiles) do not fit beside K, V and Q (100 KB): the q|k|v GEMM runs in two
-//     passes over a 36 KB operand buffer -- token tiles 0..5 with the query projection, then tiles 6..9, whose tokens wait
+//   * LDS: the split tokens (40 / 60 KB for 10 token tiles) do not fit beside K, V and Q (100 KB): the q|k|v GEMM runs in two
+//     passes over a 36 KB operand buffer (laid out for three terms; two-term operands use the first two thirds) -- token tiles 0..5 with the query projection, then tiles 6..9, whose tokens wait
 //     in registers meanwhile; both passes give every wave the same number of tiles (4 + 2).
 //   * the query frame is kept in fp32 as well ([4][64][16], the residual x + proj(.)); pixels outside every dilated
 //     window ride in token columns 49..63 as in winblock.h.

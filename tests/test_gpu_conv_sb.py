@@ -260,3 +260,37 @@ def test_range_of_the_two_term_format(model_a):
     ref = ref_of(tiny)
     y2 = run(tiny, 2)
     assert maxabs(y2.double(), ref) <= 1e-5 * float((ref - ref.mean()).abs().max()) + 2e-7
+
+
+def test_two_dimensional_tiles_on_odd_maps(model_a):
+    """The 32- and 64-output-channel 5x5 convolutions (head, encoder 0, decoder 2) run on 2-D pixel tiles of 16 x 16 / 8 x 16
+    (8 or 32 columns where that covers the map better): maps whose height and width are not multiples of the tile, narrower than
+    a tile, a single tile row -- against torch's convolution."""
+    from tests.util import golden_inputs
+    from bde2vid_amd import ops
+    from oracle import bde2vid_oracle as O
+    cfg, sd, m = model_a
+    m([{'events': torch.from_numpy(x).cuda()} for x in golden_inputs(16, 1, 5, 184, 240, 77)])     # a workspace with room for the split images
+    for (N, H, W, seed) in ((9, 47, 61, 1200), (4, 100, 77, 1201), (2, 16, 600, 1202), (1, 200, 90, 1203), (40, 21, 20, 1204)):
+        x = torch.from_numpy(dense_like((N, 5, H, W), seed))
+        with torch.no_grad():
+            ref = O.conv_layer(x, sd[O.P + 'head.conv2d.weight'], sd[O.P + 'head.conv2d.bias'], 1, 'relu')
+        y = ops.head(m, x.cuda())
+        assert m.get_info('sb_head') == 1, (N, H, W)
+        assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), ('head', N, H, W)
+    for (N, H, W, seed) in ((10, 74, 90, 1210), (8, 66, 130, 1211), (3, 34, 490, 1212), (24, 38, 36, 1213)):
+        x = torch.from_numpy(dense_like((N, 32, H, W), seed))
+        for d, name in enumerate(('forward_encoder', 'backward_encoder')):
+            with torch.no_grad():
+                ref = O.conv_layer(x, sd[f'{O.P}{name}.0.conv.conv2d.weight'], sd[f'{O.P}{name}.0.conv.conv2d.bias'], 2, 'relu')
+            y = ops.encoder_conv(m, 0, d, x.cuda())
+            assert m.get_info('sb_enc0') == 1, (N, H, W)
+            assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), ('enc0', name, N, H, W)
+    for (N, H, W, seed) in ((3, 37, 45, 1220), (2, 8, 301, 1221), (6, 23, 22, 1222)):
+        x = torch.from_numpy(dense_like((N, 64, H, W), seed))
+        skip = torch.from_numpy(dense_like((N, 64, H, W), seed + 50))
+        with torch.no_grad():
+            ref = O.upsample_conv_layer(skip + x, sd[O.P + 'decoders.2.1.conv2d.weight'], sd[O.P + 'decoders.2.1.conv2d.bias'])
+        y = ops.decoder(m, 2, x.cuda(), skip.cuda())
+        assert m.get_info('sb_dec2') == 1, (N, H, W)
+        assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), ('dec2', N, H, W)
