@@ -81,6 +81,12 @@ __device__ __forceinline__ void ws_split_pair(float x0, float x1, unsigned (&t)[
     }
 }
 
+// Experiment switch (tools/build_variant.sh ... -DWS_ATTN_KEY_OUTER=1): key tile outermost in the attention phase, a key tile's V
+// rows read once for the three query tiles (40 LDS reads per wave instead of 120).  Measured on one box: attention phase
+// 28.8 k -> 30.7 k cycles, 32.2 -> 32.9 us per launch -- the V reads are not what the phase waits on.  Off.
+#ifndef WS_ATTN_KEY_OUTER
+#define WS_ATTN_KEY_OUTER 0
+#endif
 // two-term weights are packed times a power of two (split.h): the accumulator of GEMM i is multiplied by a.unscale[i]
 #define WS_US(x, i) (TERMS == 2 ? (x) * a.unscale[i] : (x))
 template <int TERMS>
@@ -326,9 +332,15 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             for (int i = 0; i < NQT; ++i) qf[i] = QL[(i * WB_C + h * WB_HD + g4) * 16 + col];
             const f32x4* bf = reinterpret_cast<const f32x4*>(a.biasF + (long)h * 4 * WB_NT * 256) + lane;
             constexpr int HT = WB_NT / 2;
+#if WS_ATTN_KEY_OUTER
+            f32x4 sb[2][NQT];                                          // bias of the three query tiles x (this, next) key tile
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) sb[0][i] = bf[(i * WB_NT) * 64];
+#else
             f32x4 sc[2][HT];
 #pragma unroll
             for (int j = 0; j < HT; ++j) sc[0][j] = bf[j * 64];
+#endif
             float s48[4];
             {
                 const int jt = min(col, WB_NT - 1);
@@ -338,6 +350,55 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             }
             const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
             float pm[NQT], pl[NQT], po[NQT][4];                        // per query tile: max, sum, p*v of this lane's keys
+#if WS_ATTN_KEY_OUTER
+            // Key tile outermost: the V rows of a key tile (four 16-byte LDS reads per lane, 1 KiB per wave instruction whatever
+            // the lanes share) are fetched ONCE and used by the three query tiles -- 40 reads per wave instead of 120, the LDS
+            // return path being what the 16 waves of a window queue on.  Online softmax per (key tile, query tile): the running
+            // maximum may move at every tile (one v_exp and five multiplies more per tile than the two-halves form below).
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) { pm[i] = -INFINITY; pl[i] = 0.f; po[i][0] = po[i][1] = po[i][2] = po[i][3] = 0.f; }
+            {
+                f32x4 vb[2][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vb[0][r] = *reinterpret_cast<const f32x4*>(vbase + r * WB_VP);
+#pragma unroll
+                for (int jt = 0; jt < WB_NT; ++jt) {
+                    const int cb = jt & 1, nx = cb ^ 1;
+                    if (jt + 1 < WB_NT) {
+#pragma unroll
+                        for (int i = 0; i < NQT; ++i) sb[nx][i] = bf[(i * WB_NT + jt + 1) * 64];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vb[nx][r] = *reinterpret_cast<const f32x4*>(vbase + ((jt + 1) * 16 + r) * WB_VP);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NQT; ++i) sb[cb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt], qf[i], sb[cb][i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NQT; ++i) {
+                        const f32x4 s4 = sb[cb][i];
+                        float m2 = wb_max3(pm[i], s4[0], s4[1]);
+                        m2 = wb_max3(m2, s4[2], s4[3]);
+                        const float corr = __builtin_amdgcn_exp2f(pm[i] - m2);          // (first tile: 2^(-inf) = 0 on zeros)
+                        pm[i] = m2;
+                        float pr[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(s4[r] - m2);
+                        float l = pl[i] * corr, o0 = po[i][0] * corr, o1 = po[i][1] * corr, o2 = po[i][2] * corr, o3 = po[i][3] * corr;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 v = vb[cb][r];
+                            l += pr[r];
+                            o0 += pr[r] * v[0];
+                            o1 += pr[r] * v[1];
+                            o2 += pr[r] * v[2];
+                            o3 += pr[r] * v[3];
+                        }
+                        pl[i] = l; po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int i = 0; i < NQT; ++i) {
                 float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
@@ -392,6 +453,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 }
                 pm[i] = mx; pl[i] = l; po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
             }
+#endif
             // ---- query 48: keys on the lanes ----------------------------------------------------------
             float l48, o48[4];
             {

@@ -286,7 +286,7 @@ def test_two_dimensional_tiles_on_odd_maps(model_a):
             y = ops.encoder_conv(m, 0, d, x.cuda())
             assert m.get_info('sb_enc0') == 1, (N, H, W)
             assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), ('enc0', name, N, H, W)
-    for (N, H, W, seed) in ((3, 37, 45, 1220), (2, 8, 301, 1221), (6, 23, 22, 1222)):
+    for (N, H, W, seed) in ((3, 37, 45, 1220), (2, 8, 301, 1221), (9, 23, 22, 1222)):
         x = torch.from_numpy(dense_like((N, 64, H, W), seed))
         skip = torch.from_numpy(dense_like((N, 64, H, W), seed + 50))
         with torch.no_grad():
