@@ -444,6 +444,29 @@ static long pack16_split(Arena& ar, const float* w, int rows, int K, int terms, 
     return off;
 }
 
+// tokgemm_sb_kernel (wideblock.h): rows x K as two fp16 terms, A-fragment order of the 16x16x32 MFMA, k in the order a lane of a
+// FRAG16 tensor holds two consecutive channel groups: element jj of lane (m, g4) of k-step ks = W[16 rt + m][32 ks + (jj < 4 ?
+// 4 jj + g4 : 16 + 4 (jj - 4) + g4)].  [row tile 16][k-step 32][term][64 lanes][8]; K % 32 == 0.
+static long pack16_split_frag(Arena& ar, const float* w, int rows, int K, long unscale_off) {
+    const int nrt = cdiv(rows, 16), nks = K / 32;
+    const long n_u16 = (long)nrt * nks * 2 * 64 * 8;
+    const long off = ar.alloc(n_u16 / 2);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + off);
+    const float scale = sb_weight_scale(w, (long)rows * K);
+    ar.host[unscale_off] = 1.f / scale;
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int r = rt * 16 + (l & 15), g4 = l >> 4;
+                    const int k = ks * 32 + (jj < 4 ? 4 * jj + g4 : 16 + 4 * (jj - 4) + g4);
+                    unsigned short t3[3];
+                    split_terms(r < rows ? w[(long)r * K + k] : 0.f, 2, scale, t3);
+                    for (int t = 0; t < 2; ++t) dst[((((long)rt * nks + ks) * 2 + t) * 64 + l) * 8 + jj] = t3[t];
+                }
+    return off;
+}
+
 // Weight fragments of the recurrent step kernel (lstm16.h):
 // [hidden16 block][chunk of 8 channels][tap][k4][64 lanes][gate], lane l = W[gate*Ch + hb*16 + (l&15)][chunk*8 + k4*4 + (l>>4)][tap]
 // (the four gate fragments of a lane are adjacent: one 16-byte LDS read fetches them).
@@ -644,6 +667,7 @@ struct AttnLevel {
     std::vector<AttnBlock> blocks;
     PackedLayer kvall;      // rows = depth*2C: K|V of every block for a non-query frame
     long kvallW = -1;       // the same rows packed for wideblock.h
+    long kvallH = -1, kvallH_unscale = -1;   // ... and as two fp16 terms for tokgemm_sb_kernel (k order of FRAG16 group pairs)
 };
 
 struct Workspace {
@@ -748,6 +772,7 @@ struct bde_model {
     hipStream_t dir_stream[4] = {};         // per workspace slot: the second direction's stream and its fork / join events
     hipEvent_t dir_fork[4] = {}, dir_join[4] = {};
     int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
+    int wide_kv_sb = 1;           // K|V GEMMs of the head_dim-16 chain on two-term split operands (tokgemm_sb_kernel, wideblock.h)
     int lstm_fuse_x = 1;          // ... and the x-part of the gates in the same contraction (no batched gate convolution, no gx round trip)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
@@ -1133,7 +1158,11 @@ static int build_packed(bde_model* m) {
             }
         }
         al.kvall = pack_layer(ar, {&kvall}, false);
-        if (C % 64 == 0 && hd == 16) al.kvallW = pack16x4(ar, kvall.w.data(), kvall.rows, C);
+        if (C % 64 == 0 && hd == 16) {
+            al.kvallW = pack16x4(ar, kvall.w.data(), kvall.rows, C);
+            al.kvallH_unscale = ar.alloc(4);
+            al.kvallH = pack16_split_frag(ar, kvall.w.data(), kvall.rows, C, al.kvallH_unscale);
+        }
     }
     for (int j = 0; j < L; ++j) {
         const int cin = m->cout(L - 1 - j), cout = m->cin(L - 1 - j);
@@ -1990,7 +2019,7 @@ static bool wide_ok(const bde_model* m, int l) {
 // One GEMM of the wide chain (wideblock.h): x FRAG16 [B][ntile][K/16][256] -> token-major or FRAG16
 static int run_tokgemm(bde_model* m, const char* span, int l, long w_off, const PackedLayer& pl, int M, int K, const float* x, int B,
                        long HW, float* out_tok, float* out_frag, int act, const float* res, const float* addres, float* out_nchw,
-                       int mask_w, int mask_pt, int mask_pl, long row_off, hipStream_t s) {
+                       int mask_w, int mask_pt, int mask_pl, long row_off, hipStream_t s, long wH_off = -1, long wH_unscale = -1) {
     TokGemmArgs a;
     memset(&a, 0, sizeof a);
     const int ntile = (int)cdivl(HW, 16);
@@ -2011,6 +2040,11 @@ static int run_tokgemm(bde_model* m, const char* span, int l, long w_off, const 
     a.act = act;
     a.mask_w = mask_w; a.mask_pt = mask_pt; a.mask_pl = mask_pl;
     ProfScope ps(m, pname(span, l), s);
+    if (wH_off >= 0 && m->wide_kv_sb && m->sb_terms == 2 && row_off == 0) {      // two fp16 terms on the matrix cores (tokgemm_sb_kernel)
+        a.wS = reinterpret_cast<const unsigned short*>(m->P(wH_off));
+        a.w_unscale = m->P(wH_unscale);
+        if (tokgemm_sb_fits(a)) return tokgemm_sb_launch(a, B, s);
+    }
     return tokgemm_launch(a, B, s);
 }
 
@@ -2122,7 +2156,7 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         { ProfScope ps(m, pname("to_frag", l), s); BDE_TRY(nchw_to_frag(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s)); }
         if (need_un)
             BDE_TRY(run_tokgemm(m, "wide_kv_all", l, al.kvallW, al.kvall, al.depth * 2 * C, C, ws.mergedT[l], T * B, HW, ws.kvun[l],
-                                nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+                                nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
         if (!m->wide_fuse_qkv)
             BDE_TRY(run_tokgemm(m, "wide_qkv_all", l, al.blocks[0].qkvW, al.blocks[0].qkv, 3 * C, C, ws.mergedT[l], T * B, HW, ws.qkv0[l],
                                 nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
@@ -2139,7 +2173,7 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
                                              ws.qkv0[l] + (long)t * q0fs, s));
             if (need_ref && t + 1 < T)
                 BDE_TRY(run_tokgemm(m, "wide_kv", l, al.kvallW, al.kvall, al.depth * 2 * C, C, mtF, B, HW, ws.kvref[l] + (long)t * kvfs,
-                                    nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+                                    nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
             if (on_frame) BDE_TRY(on_frame(m, t, ctx));
         }
         return BDE_OK;
@@ -2754,6 +2788,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "wide_fuse_qkv") { m->wide_fuse_qkv = (int)value; return BDE_OK; }
+    if (std::string(key) == "wide_kv_sb") { m->wide_kv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") {
         if (m->conv_sb != (int)value)
             for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it
@@ -3182,7 +3217,7 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
             if (d == c.q_idx) continue;
             float* dst = w.kvun[level] + (long)d * kvfs;
             BDE_TRY(run_tokgemm(m, "wide_kv", level, al.kvallW, al.kvall, al.depth * 2 * C, C, fr, B, HW, dst, nullptr, ACT_NONE, nullptr,
-                                nullptr, nullptr, 0, 0, 0, 0, s));
+                                nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
             kvslot[d] = dst;
         }
         float* qf = w.mergedT[level] + (long)c.q_idx * ffs;

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "token_fused.h"
+#include "winblock_sb.h"        // ws_split_pair
 
 namespace bde {
 
@@ -86,6 +87,11 @@ struct TokGemmArgs {
     int K, M, HW, ntile;
     int act;               // ACT_NONE | ACT_GELU
     int mask_w, mask_pt, mask_pl;    // dilated-window coverage mask (DTransformer.py:79-82): uncovered pixels get the residuals only
+    // tokgemm_sb_kernel: the weights as two fp16 terms (split.h) in A-fragment order of the 16x16x32 MFMA with the k order of a
+    // PAIR of FRAG16 channel groups, [M/16][K/32][2 terms][64 lanes][8]: lane l = (row m = l & 15, g4 = l >> 4), element jj =
+    // W[16 rt + m][32 ks + (jj < 4 ? 4 jj + g4 : 16 + 4 (jj - 4) + g4)] * 2^e;  *w_unscale = 2^-e
+    const unsigned short* wS;
+    const float* w_unscale;
 };
 
 // A wave computes MT row tiles x NT token tiles over 1/KSPLIT of K.  KSPLIT == 1: the four waves of a workgroup take
@@ -317,6 +323,128 @@ static int tokgemm_launch_t(const TokGemmArgs& a, int B, hipStream_t s) {
     const int ngm = a.M / 16;
     dim3 grid(cdiv(a.ntile, NT), KSPLIT == 1 ? cdiv(ngm, 4 * MT) : cdiv(ngm, MT), B);
     hipLaunchKernelGGL((tokgemm_kernel<MT, NT, KSPLIT, PRE>), grid, dim3(256), 0, s, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+// The K|V GEMMs of the chain (token-major output, LayerNorm folded; K = C = 256, M = depth * 2C = 3072 at level 2 of config A) on
+// the fp16 matrix cores with two-term split operands (split.h): a wave = MT row tiles x one token tile.  The tokens stay in
+// FRAG16 (fp32): a lane's float4s of two consecutive channel groups ARE eight k values of the 16x16x32 MFMA's B operand once the
+// weights are packed in that k order, so the only extra work is their split into two fp16 terms (three vector instructions
+// per value, shared by the wave's MT row tiles) -- 3 MFMAs of 16 cycles per 32 k against 8 of 32 cycles.
+template <int MT>
+__global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g4 = lane >> 4, col = lane & 15;
+    const int b = blockIdx.z;
+    const int ngk = a.K >> 4, ngm = a.M >> 4, nks = a.K >> 5;
+    const int rt0 = (blockIdx.y * 4 + wave) * MT;
+    const int tile = blockIdx.x;
+    if (rt0 >= ngm) return;
+    const wf4* xp = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)tile * ngk) * 64 + lane;
+    const sb8* wp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wp[m] = reinterpret_cast<const sb8*>(a.wS) + ((long)min(rt0 + m, ngm - 1) * nks * 2) * 64 + lane;
+    // epilogue operands: with the operand stream on the short launches of the sequential chain (a load issued after the MFMA
+    // loop is a round trip on their critical path), after it on the T-batched one (64 registers it cannot spare)
+    float bb[MT][4], ss[MT][4];
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row0 = min(rt0 + m, ngm - 1) * 16 + g4 * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bb[m][r] = a.bias[row0 + r];
+                ss[m][r] = a.lnsum ? a.lnsum[row0 + r] : 0.f;
+            }
+        }
+    };
+    if (MT < 8) load_rows();
+    const float unscale = a.w_unscale[0];
+    constexpr int KS = 8;                                   // k-steps of 32 (K = 256); longer K loops over groups of KS
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+    for (int k0 = 0; k0 < nks; k0 += KS) {
+        wf4 xv[KS][2];                                      // the token operand of the whole group goes out first
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int ks = min(k0 + k, nks - 1);
+            xv[k][0] = xp[(long)(2 * ks) * 64];
+            xv[k][1] = xp[(long)(2 * ks + 1) * 64];
+        }
+        sb8 av[2][MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[0][m][t] = wp[m][((long)k0 * 2 + t) * 64];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k + 1 < KS) {
+                const int ks = min(k0 + k + 1, nks - 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) av[(k + 1) & 1][m][t] = wp[m][((long)ks * 2 + t) * 64];
+            }
+            if (k0 + k < nks) {
+                const wf4 x0 = xv[k][0], x1 = xv[k][1];
+                s1 += ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+                s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+                      ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
+                unsigned t[4][2];
+                ws_split_pair<2>(x0[0], x0[1], t[0]);
+                ws_split_pair<2>(x0[2], x0[3], t[1]);
+                ws_split_pair<2>(x1[0], x1[1], t[2]);
+                ws_split_pair<2>(x1[2], x1[3], t[3]);
+                sb8 bfr[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = sb_mma16<2>(av[k & 1][m], bfr, acc[m]);
+            }
+        }
+    }
+    if (MT >= 8) load_rows();
+    // LayerNorm statistics of each lane's token: the four g4 lanes of a column hold the four channel residues
+    float mu = 0.f, rstd = 1.f;
+    if (a.lnsum) {
+        float u = s1, v = s2;
+        u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+        u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+        const float mean = u / (float)a.K;
+        const float var = fmaxf(v / (float)a.K - mean * mean, 0.f);
+        mu = mean;
+        rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+    }
+    const int tok = tile * 16 + col;
+    if (tok >= a.HW) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int rt = rt0 + m;
+        if (rt >= ngm) continue;
+        const int row0 = rt * 16 + g4 * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float y = acc[m][r] * unscale;
+            if (a.lnsum) y = rstd * (y - mu * ss[m][r]);
+            v[r] = act_apply(y + bb[m][r], a.act);
+        }
+        *reinterpret_cast<float4*>(a.out_tok + b * a.out_bs + (long)tok * a.M + row0) = float4{v[0], v[1], v[2], v[3]};
+    }
+}
+static bool tokgemm_sb_fits(const TokGemmArgs& a) {
+    return a.wS != nullptr && a.out_tok != nullptr && a.res == nullptr && a.addres == nullptr && a.K % 32 == 0 && a.M % 16 == 0 && a.mask_w == 0;
+}
+static int tokgemm_sb_launch(const TokGemmArgs& a, int B, hipStream_t s) {
+    const int ngm = a.M / 16;
+    const long tiles = (long)a.ntile * ngm * B;
+    // (eight row tiles per wave would halve the split work per MFMA on the T-batched launch, but need 239 + 32 registers: one wave
+    //  per SIMD; four row tiles: 212, two waves)
+    (void)tiles;
+    hipLaunchKernelGGL(tokgemm_sb_kernel<4>, dim3(a.ntile, cdiv(ngm, 16), B), dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
