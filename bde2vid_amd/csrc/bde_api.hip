@@ -658,6 +658,7 @@ struct AttnBlock {
     long projS = -1, fc1S = -1, fc2S = -1, qkvS = -1;         // split packings for winblock_sb.h, three bf16 terms
     long projH = -1, fc1H = -1, fc2H = -1, qkvH = -1;         // two fp16 terms; unscaleH -> {q|k|v, proj, fc1, fc2} inverse scales
     long unscaleH = -1;                                       // (four floats in the packed image)
+    long qkvHF = -1, qkvHF_unscale = -1;                      // q|k|v as two fp16 terms in FRAG16 k order (attn_tok16_kernel<true, true>)
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -1138,6 +1139,8 @@ static int build_packed(bde_model* m) {
                 ab.fc1W = pack16x4(ar, fc1.w.data(), hid, C);
                 ab.fc2W = pack16x4(ar, fc2.w.data(), C, hid);
                 ab.qkvW = pack16x4(ar, qkv.w.data(), 3 * C, C);
+                ab.qkvHF_unscale = ar.alloc(4);
+                ab.qkvHF = pack16_split_frag(ar, qkv.w.data(), 3 * C, C, ab.qkvHF_unscale);
             }
             if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
                 ab.projS = pack16_split(ar, proj.w.data(), C, C, 3, -1);
@@ -2083,6 +2086,10 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
             a.bqkv = m->P(ab.qkv.b_off);
             a.sqkv = m->P(ab.qkv.s_off);
             a.q_slot = c.q_idx;
+            if (m->wide_kv_sb && m->sb_terms == 2 && ab.qkvHF >= 0) {          // q|k|v on two fp16 terms (wideblock.h)
+                a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(ab.qkvHF));
+                a.wqkv_unscale = m->P(ab.qkvHF_unscale);
+            }
         }
         a.q = qkv;
         a.q_bs = HW * 3 * C;

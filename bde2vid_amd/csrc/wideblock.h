@@ -484,6 +484,9 @@ struct AttnTokArgs {
     const float* bqkv;            // [3C] folded biases
     const float* sqkv;            // [3C] row sums of the folded weights
     int q_slot;                   // buffer slot of the query frame
+    // SPLIT: the same rows as two fp16 terms in the k order of FRAG16 group pairs (TokGemmArgs::wS), *wqkv_unscale their inverse scale
+    const unsigned short* wqkvS;
+    const float* wqkv_unscale;
 };
 
 // softmax(q k^T + bias) v for one (window, head), head_dim 16; four waves = four tiles of 16 queries (attn_mfma.h).
@@ -494,7 +497,9 @@ struct AttnTokArgs {
 // fragment is one 16-byte load per lane and channel group) -- instead of a GEMM launch of its own in front of this one
 // (8.9 us on the sequential chain for 0.36 GFLOP).  The D fragments ARE what the attention wants: q as the score MFMA's B
 // operand, K and V as the LDS rows below; the per-(window, head) split repeats no work.
-template <bool FUSE>
+// SPLIT (with FUSE): that GEMM on the fp16 matrix cores with two-term operands (split.h), the window tokens split in registers as in
+// tokgemm_sb_kernel: 72 MFMAs of 16 cycles per wave instead of 192 of 32.
+template <bool FUSE, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
     constexpr int HD = 16, NT = 10;
     __shared__ __align__(16) float KL[NT * HD * 16];
@@ -525,7 +530,62 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
         f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
         float s1 = 0.f, s2 = 0.f;
         const bool any = wave * 16 < ATT_TOK;                      // (tile 3 holds token 48 only; a tile past the window is skipped)
-        if (any) {
+        if (SPLIT && any) {
+            const int nks = a.C >> 5;
+            const sb8* wqS = reinterpret_cast<const sb8*>(a.wqkvS) + ((long)head * nks * 2) * 64 + lane;
+            const sb8* wkS = reinterpret_cast<const sb8*>(a.wqkvS) + ((long)(ngk + head) * nks * 2) * 64 + lane;
+            const sb8* wvS = reinterpret_cast<const sb8*>(a.wqkvS) + ((long)(2 * ngk + head) * nks * 2) * 64 + lane;
+            constexpr int U = 2;                                   // k-steps of 32 (two channel groups each) per register buffer
+            wf4 xb[2][2 * U];
+            sb8 fq[2][U][2], fk[2][U][2], fv[2][U][2];
+            auto fetch = [&](int buf, int ks0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long ks = min(ks0 + u, nks - 1);
+                    xb[buf][2 * u] = xw[(2 * ks) * 64];
+                    xb[buf][2 * u + 1] = xw[(2 * ks + 1) * 64];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        fq[buf][u][t] = wqS[(ks * 2 + t) * 64];
+                        fk[buf][u][t] = wkS[(ks * 2 + t) * 64];
+                        fv[buf][u][t] = wvS[(ks * 2 + t) * 64];
+                    }
+                }
+            };
+            auto compute = [&](int buf, int ks0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (ks0 + u >= nks) continue;
+                    wf4 x0 = xb[buf][2 * u], x1 = xb[buf][2 * u + 1];
+                    if (qpix < 0) x0 = x1 = wf4{0.f, 0.f, 0.f, 0.f};
+                    s1 += ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+                    s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+                          ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
+                    unsigned t[4][2];
+                    ws_split_pair<2>(x0[0], x0[1], t[0]);
+                    ws_split_pair<2>(x0[2], x0[3], t[1]);
+                    ws_split_pair<2>(x1[0], x1[1], t[2]);
+                    ws_split_pair<2>(x1[2], x1[3], t[3]);
+                    sb8 bfr[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+                    aq = sb_mma16<2>(fq[buf][u], bfr, aq);
+                    ak = sb_mma16<2>(fk[buf][u], bfr, ak);
+                    av = sb_mma16<2>(fv[buf][u], bfr, av);
+                }
+            };
+            fetch(0, 0);
+            for (int ks = 0; ks < nks; ks += 2 * U) {
+                if (ks + U < nks) fetch(1, ks + U);
+                compute(0, ks);
+                if (ks + 2 * U < nks) fetch(0, ks + 2 * U);
+                if (ks + U < nks) compute(1, ks + U);
+            }
+            const float us = a.wqkv_unscale[0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { aq[r] *= us; ak[r] *= us; av[r] *= us; }
+        }
+        if (!SPLIT && any) {
             // two register buffers of U channel groups (literal indices only): the next batch of operand fragments is in flight
             // during the MFMAs of the current one -- a workgroup has the CU almost to itself, nobody else covers an L2 round trip
             constexpr int U = 4;
@@ -662,8 +722,9 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
 
 static int attn_tok16_launch(const AttnTokArgs& a, int B, hipStream_t s) {
     const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
-    if (a.x) hipLaunchKernelGGL(attn_tok16_kernel<true>, dim3(nW, a.heads, B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attn_tok16_kernel<false>, dim3(nW, a.heads, B), dim3(256), 0, s, a);
+    if (a.x && a.wqkvS && a.C % 32 == 0) hipLaunchKernelGGL((attn_tok16_kernel<true, true>), dim3(nW, a.heads, B), dim3(256), 0, s, a);
+    else if (a.x) hipLaunchKernelGGL((attn_tok16_kernel<true, false>), dim3(nW, a.heads, B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_tok16_kernel<false, false>), dim3(nW, a.heads, B), dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
