@@ -659,6 +659,7 @@ struct AttnBlock {
     long projH = -1, fc1H = -1, fc2H = -1, qkvH = -1;         // two fp16 terms; unscaleH -> {q|k|v, proj, fc1, fc2} inverse scales
     long unscaleH = -1;                                       // (four floats in the packed image)
     long qkvHF = -1, qkvHF_unscale = -1;                      // q|k|v as two fp16 terms in FRAG16 k order (attn_tok16_kernel<true, true>)
+    long projHF = -1, fc1HF = -1, mlpHF_unscale = -1;         // proj, fc1 likewise (projfc1_sb_kernel); unscale: {proj, fc1}
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -773,6 +774,7 @@ struct bde_model {
     hipStream_t dir_stream[4] = {};         // per workspace slot: the second direction's stream and its fork / join events
     hipEvent_t dir_fork[4] = {}, dir_join[4] = {};
     int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
+    int wide_fuse_mlp = 1;        // ... and x1 = x + proj(.) together with GELU(fc1(LN(x1))) in one launch (projfc1_sb_kernel)
     int wide_kv_sb = 1;           // K|V GEMMs of the head_dim-16 chain on two-term split operands (tokgemm_sb_kernel, wideblock.h)
     int lstm_fuse_x = 1;          // ... and the x-part of the gates in the same contraction (no batched gate convolution, no gx round trip)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
@@ -1141,6 +1143,9 @@ static int build_packed(bde_model* m) {
                 ab.qkvW = pack16x4(ar, qkv.w.data(), 3 * C, C);
                 ab.qkvHF_unscale = ar.alloc(4);
                 ab.qkvHF = pack16_split_frag(ar, qkv.w.data(), 3 * C, C, ab.qkvHF_unscale);
+                ab.mlpHF_unscale = ar.alloc(4);
+                ab.projHF = pack16_split_frag(ar, proj.w.data(), C, C, ab.mlpHF_unscale);
+                ab.fc1HF = pack16_split_frag(ar, fc1.w.data(), hid, C, ab.mlpHF_unscale + 1);
             }
             if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
                 ab.projS = pack16_split(ar, proj.w.data(), C, C, 3, -1);
@@ -2113,11 +2118,31 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
         { ProfScope ps(m, pname("wide_core", l), s); BDE_TRY(attn_tok16_launch(a, B, s)); }
         float* dst = (last && out) ? out : (x == ws.xa ? ws.xb : ws.xa);     // out == nullptr: the caller only wants out_nchw
         // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only; DTransformer.py:299, 79-82)
+        // hidden = GELU(fc1(LN(x1))): with two-term operands both in one launch (projfc1_sb_kernel)
+        if (m->wide_fuse_mlp && m->sb_terms == 2 && ab.projHF >= 0 && C == 256 && ab.fc1.Cout == 4 * C) {
+            ProjFc1Args pa;
+            memset(&pa, 0, sizeof pa);
+            pa.ao = ws.ao; pa.x = x; pa.x1 = ws.x1; pa.hid = ws.hid;
+            pa.wprojS = reinterpret_cast<const unsigned short*>(m->P(ab.projHF));
+            pa.wfc1S = reinterpret_cast<const unsigned short*>(m->P(ab.fc1HF));
+            pa.proj_unscale = m->P(ab.mlpHF_unscale);
+            pa.fc1_unscale = m->P(ab.mlpHF_unscale + 1);
+            pa.bproj = m->P(ab.proj.b_off);
+            pa.bfc1 = m->P(ab.fc1.b_off);
+            pa.sfc1 = m->P(ab.fc1.s_off);
+            pa.x_bs = (long)ntile * 16 * C;
+            pa.hid_bs = (long)ntile * 16 * 4 * C;
+            pa.C = C; pa.hidden = 4 * C; pa.HW = (int)HW; pa.ntile = ntile;
+            pa.mask_w = dil ? W : 0; pa.mask_pt = pt; pa.mask_pl = plft;
+            ProfScope ps(m, pname("wide_projfc", l), s);
+            BDE_TRY(projfc1_sb_launch(pa, B, s));
+        } else {
         BDE_TRY(run_tokgemm(m, "wide_proj", l, ab.projW, ab.proj, C, C, ws.ao, B, HW, nullptr, ws.x1, ACT_NONE, x, nullptr, nullptr,
                             dil ? W : 0, pt, plft, 0, s));
         // x2 = x1 + fc2(GELU(fc1(LN(x1))))  (+ merged[t] after the last block; DTransformer.py:279-283,304, V5.py:166)
         BDE_TRY(run_tokgemm(m, "wide_mlp_in", l, ab.fc1W, ab.fc1, 4 * C, C, ws.x1, B, HW, nullptr, ws.hid, ACT_GELU, nullptr, nullptr,
                             nullptr, 0, 0, 0, 0, s));
+        }
         BDE_TRY(run_tokgemm(m, "wide_mlp_out", l, ab.fc2W, ab.fc2, C, 4 * C, ws.hid, B, HW, nullptr, dst, ACT_NONE, ws.x1,
                             last ? addres : nullptr, last ? out_nchw : nullptr, 0, 0, 0, 0, s));
         x = dst;
@@ -2796,6 +2821,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     }
     if (std::string(key) == "wide_fuse_qkv") { m->wide_fuse_qkv = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_kv_sb") { m->wide_kv_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "wide_fuse_mlp") { m->wide_fuse_mlp = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") {
         if (m->conv_sb != (int)value)
             for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it

@@ -449,6 +449,160 @@ static int tokgemm_sb_launch(const TokGemmArgs& a, int B, hipStream_t s) {
     return BDE_OK;
 }
 
+// x1 = x + proj(attention output) AND hidden = GELU(fc1(LayerNorm2(x1))) in ONE launch of the sequential chain
+// (DTransformer.py:299, 279-283): fc1 needs every channel of a token's x1, so the two GEMMs used to be two launches of 8-9 us for
+// 0.09 + 0.36 GFLOP.  With two-term operands (split.h) the proj of a 16-token tile is 384 MFMAs of 16 cycles: cheap enough to
+// REPEAT in each of the four workgroups that share a token tile's fc1 rows (grid = token tiles x 4 quarters of the hidden rows).
+// A workgroup: proj of its token tile (16 row tiles over four waves) -> x1 into LDS in FRAG16 order (quarter 0 also stores it: the
+// residual of fc2) + LayerNorm sums -> barrier -> its 16 fc1 row tiles with x1 as the token operand, GELU, FRAG16 store.
+// Token operands are split in registers as in tokgemm_sb_kernel; weights in the k order of FRAG16 group pairs (TokGemmArgs::wS).
+// C = 256, hidden = 1024 (level 2 of config A).
+struct ProjFc1Args {
+    const float* ao;              // FRAG16 [B][ntile][C/16][256]: attention output
+    const float* x;               // FRAG16, same shape: the block input (shortcut)
+    const unsigned short *wprojS, *wfc1S;
+    const float *proj_unscale, *fc1_unscale;
+    const float* bproj;           // [C]
+    const float *bfc1, *sfc1;     // [hidden] folded bias, row sums of the LayerNorm-folded weights
+    float* x1;                    // FRAG16 [B][ntile][C/16][256]
+    float* hid;                   // FRAG16 [B][ntile][hidden/16][256]
+    long x_bs, hid_bs;
+    int C, hidden, HW, ntile;
+    int mask_w, mask_pt, mask_pl; // dilated-window coverage mask on the proj output (uncovered pixels: shortcut only)
+};
+// acc[m] += W[row tiles rt0 .. rt0 + 3] x over K = 32 nks; xp = the lane's wf4 of channel group 0 (consecutive groups 64 wf4 apart)
+template <typename XP>
+__device__ __forceinline__ void frag_gemm4(XP xp, const sb8* wbase, int rt0, int nks, f32x4 (&acc)[4]) {
+    constexpr int KS = 8;
+    const sb8* wp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wp[m] = wbase + ((long)(rt0 + m) * nks * 2) * 64;
+    for (int k0 = 0; k0 < nks; k0 += KS) {
+        wf4 xv[KS][2];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int ks = min(k0 + k, nks - 1);
+            xv[k][0] = xp[(2 * ks) * 64];
+            xv[k][1] = xp[(2 * ks + 1) * 64];
+        }
+        sb8 av[2][4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[0][m][t] = wp[m][((long)k0 * 2 + t) * 64];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k + 1 < KS) {
+                const int ks = min(k0 + k + 1, nks - 1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) av[(k + 1) & 1][m][t] = wp[m][((long)ks * 2 + t) * 64];
+            }
+            if (k0 + k < nks) {
+                const wf4 x0 = xv[k][0], x1 = xv[k][1];
+                unsigned t[4][2];
+                ws_split_pair<2>(x0[0], x0[1], t[0]);
+                ws_split_pair<2>(x0[2], x0[3], t[1]);
+                ws_split_pair<2>(x1[0], x1[1], t[2]);
+                ws_split_pair<2>(x1[2], x1[3], t[3]);
+                sb8 bfr[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = sb_mma16<2>(av[k & 1][m], bfr, acc[m]);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void projfc1_sb_kernel(const ProjFc1Args a) {
+    __shared__ __align__(16) float X1[16 * 256];           // x1 of the token tile, FRAG16 order [C/16][64 lanes][4]
+    __shared__ float ST[4][16][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g4 = lane >> 4, col = lane & 15;
+    const int tile = blockIdx.x, quarter = blockIdx.y, b = blockIdx.z;
+    const int ngc = a.C >> 4, ngh = a.hidden >> 4, nks = a.C >> 5;
+    const int tok = tile * 16 + col;
+    // ---- x1 = x + proj(ao): row tiles 4 wave .. 4 wave + 3 -------------------------------------------------------------------
+    {
+        const wf4* ap = reinterpret_cast<const wf4*>(a.ao + b * a.x_bs) + ((long)tile * ngc) * 64 + lane;
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float xr[4][4], bp[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int rt = 4 * wave + m;
+            const long fo = ((long)tile * ngc + rt) * 256 + col * 4 + g4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xr[m][r] = a.x[b * a.x_bs + fo + r * 64];
+                bp[m][r] = a.bproj[rt * 16 + g4 * 4 + r];
+            }
+        }
+        frag_gemm4(ap, reinterpret_cast<const sb8*>(a.wprojS) + lane, 4 * wave, nks, acc);
+        bool covered = true;
+        if (a.mask_w > 0 && tok < a.HW) {
+            const int y = tok / a.mask_w, x = tok - y * a.mask_w;
+            const int rr = y + a.mask_pt, cc = x + a.mask_pl;
+            covered = !((rr < 7 && (rr & 1)) || (cc < 7 && (cc & 1)));
+        }
+        const float us = a.proj_unscale[0];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int rt = 4 * wave + m;
+            const long fo = ((long)tile * ngc + rt) * 256 + col * 4 + g4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (covered ? acc[m][r] * us + bp[m][r] : 0.f) + xr[m][r];
+                X1[(rt * 64 + col + 16 * r) * 4 + g4] = v;
+                if (quarter == 0) a.x1[b * a.x_bs + fo + r * 64] = v;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lane < 16) { ST[wave][lane][0] = s1; ST[wave][lane][1] = s2; }
+    }
+    __syncthreads();
+    // ---- hidden = GELU(fc1(LayerNorm2(x1))): row tiles 16 quarter + 4 wave .. + 3 ---------------------------------------------
+    {
+        const float u = (ST[0][col][0] + ST[1][col][0]) + (ST[2][col][0] + ST[3][col][0]);       // (fixed order: every workgroup
+        const float v = (ST[0][col][1] + ST[1][col][1]) + (ST[2][col][1] + ST[3][col][1]);       //  of a tile gets the same sums)
+        const float mean = u / (float)a.C;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(v / (float)a.C - mean * mean, 0.f) + 1e-5f);
+        const int rt0 = 16 * quarter + 4 * wave;
+        float bb[4][4], ss[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bb[m][r] = a.bfc1[(rt0 + m) * 16 + g4 * 4 + r];
+                ss[m][r] = a.sfc1[(rt0 + m) * 16 + g4 * 4 + r];
+            }
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        frag_gemm4(reinterpret_cast<const wf4*>(X1) + lane, reinterpret_cast<const sb8*>(a.wfc1S) + lane, rt0, nks, acc);
+        const float us = a.fc1_unscale[0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const long fo = ((long)tile * ngh + rt0 + m) * 256 + col * 4 + g4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                a.hid[b * a.hid_bs + fo + r * 64] = gelu_f(rstd * (acc[m][r] * us - mean * ss[m][r]) + bb[m][r]);
+        }
+    }
+}
+static int projfc1_sb_launch(const ProjFc1Args& a, int B, hipStream_t s) {
+    if (a.C != 256 || a.hidden != 1024) return fail(BDE_ERR_UNSUPPORTED, "fused proj + fc1: C = %d, hidden = %d", a.C, a.hidden);
+    hipLaunchKernelGGL(projfc1_sb_kernel, dim3(a.ntile, 4, B), dim3(256), 0, s, a);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
 inline bool wide_nt2() { return tuning().pw_force == 121; }   // (experiment switch: two token tiles per wave)
 // Decomposition of one GEMM of the chain: enough waves for the 1024 SIMDs, each with as long an MFMA chain as that allows.
 static int tokgemm_launch(const TokGemmArgs& a, int B, hipStream_t s) {

@@ -136,6 +136,8 @@ class Work:
             h, w = self.H >> (idx + 1), self.W >> (idx + 1)
             npad = (-(-h // 7) * 7) * (-(-w // 7) * 7)
             return B * 4.0 * npad * c.frame_num * 49 * C, 'mfma'
+        if base == 'chain_projfc':
+            return B * hw * 2.0 * (C * C + 4 * C * C), 'mfma'
         if base == 'chain_proj':
             return B * hw * 2.0 * C * C, 'mfma'
         if base in ('chain_mlp_in', 'chain_mlp_out'):
@@ -175,6 +177,8 @@ KERNEL_OF_SPAN = [
     (r'dec_conv(\d)', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_sb.h / conv_vec.h)'),
     (r'head', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_sb.h / conv_vec.h)'),
     (r'chain_(\w+?)(\d)', r'pw_gemm_kernel|attn_mfma16_kernel|attn_core_kernel|token_fused_kernel', 'split attention path of level {1}: {0}'),
+    (r'wide_projfc(\d)', r'projfc1_sb_kernel', 'x1 = x + proj(.) and GELU(fc1(LN(x1))) of a level-{0} attention block in one launch, two-term split operands (csrc/wideblock.h)'),
+    (r'wide_kv(_all)?(\d)', r'tokgemm_sb_kernel|tokgemm_kernel', 'K|V GEMM of the level-{1} attention chain (csrc/wideblock.h: two-term split operands)'),
     (r'wide_core(\d)', r'attn_tok16_kernel', 'window-attention core of level {0}, one workgroup per (window, head) (csrc/wideblock.h)'),
     (r'wide_(\w+?)(\d)', r'tokgemm_kernel', 'token GEMM of the level-{1} attention chain: {0} (csrc/wideblock.h)'),
 ]
