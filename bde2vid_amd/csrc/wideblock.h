@@ -338,9 +338,11 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
     const int g4 = lane >> 4, col = lane & 15;
     const int b = blockIdx.z;
     const int ngk = a.K >> 4, ngm = a.M >> 4, nks = a.K >> 5;
-    const int rt0 = (blockIdx.y * 4 + wave) * MT;
-    const int tile = blockIdx.x;
-    if (rt0 >= ngm) return;
+    // the four waves of a workgroup take four token tiles for the SAME row tiles: their weight fragments are one L2 -> L1 fetch
+    // (weights are 4 x the bytes of a token tile's operand; with the waves on different rows the launch pulled 135 MB through L2)
+    const int rt0 = blockIdx.y * MT;
+    const int tile = blockIdx.x * 4 + wave;
+    if (rt0 >= ngm || tile >= a.ntile) return;
     const wf4* xp = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)tile * ngk) * 64 + lane;
     const sb8* wp[MT];
 #pragma unroll
@@ -444,7 +446,7 @@ static int tokgemm_sb_launch(const TokGemmArgs& a, int B, hipStream_t s) {
     // (eight row tiles per wave would halve the split work per MFMA on the T-batched launch, but need 239 + 32 registers: one wave
     //  per SIMD; four row tiles: 212, two waves)
     (void)tiles;
-    hipLaunchKernelGGL(tokgemm_sb_kernel<4>, dim3(a.ntile, cdiv(ngm, 16), B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tokgemm_sb_kernel<4>, dim3(cdiv(a.ntile, 4), cdiv(ngm, 4), B), dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
