@@ -137,6 +137,8 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *              pointwise tail fused (csrc/lstm_sb.h: fp32-equivalent) wherever a shape fits; 0 = the fp32 matrix-core step (lstm16.h).
  *   "lstm_fuse_x": 1 (default) lets that step contract the stacked input [x | h] itself (submodules.py:316-317): no batched
  *              gate convolution and no buffer for its result; 0 = the x-part of the gates batched over T by conv_sb.
+ *   "wide_kv_sb" / "wide_fuse_mlp": 1 (default) run, on head_dim-16 levels under "sb_terms" = 2, the K|V and q|k|v GEMMs on two-term
+ *              split operands / the proj and fc1 GEMMs of a block as one launch (csrc/wideblock.h); 0 = the fp32 launches.
  *   "winblock_sb": 1 (default) runs the four GEMM phases of that one-launch block on the 16-bit matrix cores, split
  *              operands (csrc/winblock_sb.h: fp32-equivalent); 0 = fp32 MFMAs throughout (winblock.h).
  *   "winblock": 1 (default) runs an attention block of a 64-channel / 16-head level as ONE launch
