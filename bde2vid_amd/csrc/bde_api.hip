@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -2564,6 +2565,12 @@ int bde_create(const bde_config* cfg, bde_model** out) {
     BDE_REQUIRE(out != nullptr, "null out");
     BDE_TRY(validate_config(cfg));
     bde_model* m = new bde_model();
+    // BDE_SB_TERMS=3 in the environment: every model of the process starts in the three-term bf16 operand format (split.h) --
+    // fp32's exponent range for feature maps that can pass 65519, without touching the caller's code (= set_tuning("sb_terms", 3))
+    if (const char* e = getenv("BDE_SB_TERMS")) {
+        if (e[0] == '3' && e[1] == 0) m->sb_terms = 3;
+        else if (e[0] == '2' && e[1] == 0) m->sb_terms = 2;
+    }
     m->cfg = *cfg;
     m->L = cfg->num_encoders;
     *out = m;
