@@ -2559,7 +2559,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 const char* bde_last_error(void) { return last_error_ref().c_str(); }
-int bde_abi_version(void) { return 2; }
+int bde_abi_version(void) { return 3; }   // 3: bde_debug_split, operand-format keys, packed image holds both split packings
 
 int bde_create(const bde_config* cfg, bde_model** out) {
     BDE_REQUIRE(out != nullptr, "null out");
