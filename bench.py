@@ -490,6 +490,10 @@ def main():
             mm = re.fullmatch(r'(gates_x|enc_conv|dec_conv|lstm)(\d)', nm)
             split = (bool(mm) and model.get_info(sb_key[mm.group(1)] + mm.group(2)) == 1) or \
                     (nm == 'head' and model.get_info('sb_head') == 1)                        # what the library launched
+            # level-2 chain: the K|V GEMMs and proj + fc1 run on two-term operands (csrc/wideblock.h) unless switched off; the
+            # attention core (q|k|v two-term, scores / p.v fp32) and fc2 are priced against the fp32 peak
+            if terms == 2 and re.fullmatch(r'wide_(projfc|kv|kv_all)\d', nm):
+                split = True
             k['peak'] = SPLIT_PEAK_TFLOPS[terms] if split else FP32_MFMA_PEAK_TFLOPS
             if split:
                 k['bound'] = ('mfma (fp16 matrix cores, two-term split operands: 3 MFMAs per fp32 block)' if terms == 2 else
