@@ -2897,6 +2897,8 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;
     else if (k == "lstm_sbk") *value = m->use_lstm_sbk;
     else if (k == "lstm_fuse_x") *value = m->lstm_fuse_x;
+    else if (k == "wide_kv_sb") *value = m->wide_kv_sb;
+    else if (k == "wide_fuse_mlp") *value = m->wide_fuse_mlp;
     else if (k == "sb_terms") *value = m->sb_terms;
     else if (k == "packed_numel") *value = m->dev_numel;
     else if (k == "sb_head") *value = m->head.sb_used;

@@ -492,7 +492,8 @@ def main():
                     (nm == 'head' and model.get_info('sb_head') == 1)                        # what the library launched
             # level-2 chain: the K|V GEMMs and proj + fc1 run on two-term operands (csrc/wideblock.h) unless switched off; the
             # attention core (q|k|v two-term, scores / p.v fp32) and fc2 are priced against the fp32 peak
-            if terms == 2 and re.fullmatch(r'wide_(projfc|kv|kv_all)\d', nm):
+            if terms == 2 and ((re.fullmatch(r'wide_projfc\d', nm) and model.get_info('wide_fuse_mlp') == 1) or
+                               (re.fullmatch(r'wide_(kv|kv_all)\d', nm) and model.get_info('wide_kv_sb') == 1)):
                 split = True
             k['peak'] = SPLIT_PEAK_TFLOPS[terms] if split else FP32_MFMA_PEAK_TFLOPS
             if split:

@@ -150,7 +150,7 @@ int bde_wait_outputs(bde_model* m, void* stream);
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 /* Read back the state the measurement has to be honest about: "debug_skip" (non-zero = stages skipped, results
  * invalid), "graph" (0 also after a failed capture), "graphs_live" (workspaces replaying a captured launch
- * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "sb_terms", "lstm_sb", "lstm_sbk", "lstm_fuse_x", "last_stream",
+ * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "sb_terms", "lstm_sb", "lstm_sbk", "lstm_fuse_x", "wide_kv_sb", "wide_fuse_mlp", "last_stream",
  * "device", "packed_numel"; and which convolutions the latest forward ran on split operands (csrc/conv_sb.h): "sb_head",
  * "sb_enc<l>", "sb_gx<l>" (0 when the step contracts [x | h] itself: no such launch), "sb_dec<j>" (0 / 1), and
  * "sb_lstm<l>": the recurrent steps of level l ran on the fused split-operand step kernel (csrc/lstm_sb.h).
