@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get('BDE_LIB_PATH') or os.path.join(_HERE, 'libbde2vid.so'
 
 MAX_LEVELS = 8
 MAX_FRAMES = 8
+ABI_VERSION = 4          # include/bde2vid.h; lib() refuses a library built from another revision of the header
+ERR_RANGE = -5           # BDE_ERR_RANGE
 
 
 class BdeConfig(C.Structure):
@@ -93,14 +95,25 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the ABI and the binding drift apart
             fn.restype = res
             fn.argtypes = args
+        # the .so is built ahead of time and travels beside the sources: a stale one may keep every symbol and still
+        # disagree on a signature or on the layout of bde_config
+        got = int(handle.bde_abi_version())
+        if got != ABI_VERSION and not os.environ.get('BDE_LIB_ANY_ABI'):      # (A/B timing against an older build: tools/gpu.sh ab)
+            raise RuntimeError(f'{LIB_PATH} reports ABI version {got}, this binding is written for {ABI_VERSION}: '
+                               'rebuild the library (`make`)')
         _lib = handle
     return _lib
+
+
+class RangeError(RuntimeError):
+    """BDE_ERR_RANGE: an activation left the range of the two-term operand format and "sb_auto" is 0."""
 
 
 def check(status: int):
     if status != 0:
         msg = lib().bde_last_error()
-        raise RuntimeError(f'libbde2vid error {status}: {msg.decode("utf-8", "replace") if msg else "?"}')
+        text = f'libbde2vid error {status}: {msg.decode("utf-8", "replace") if msg else "?"}'
+        raise (RangeError if status == ERR_RANGE else RuntimeError)(text)
 
 
 def make_config(cfg) -> BdeConfig:

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
 // weights per output as upsample2x_sum_kernel.
 template <int TERMS>
 __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                                   unsigned short* __restrict__ out, int C, int Hs, int Ws) {
+                                                                   unsigned short* __restrict__ out, int C, int Hs, int Ws,
+                                                                   unsigned* ovf) {
     const int Wo = 2 * Ws;
     const long HWo = 4L * Hs * Ws, HWs = (long)Hs * Ws;
     // (a wave = 64 consecutive pixels of one half: every plane load is one or two full 128-byte segments)
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* 
     const float wya = 1.f - wyb, wxa = 1.f - wxb;
     const int iaa = ya * Ws + xa, iab = ya * Ws + xb, iba = yb * Ws + xa, ibb = yb * Ws + xb;
     unsigned short t[8][TERMS];
+    float gm = 0.f;                                        // range guard of the two-term format (split.h)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = c16 * 16 + half * 8 + q;
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* 
             }
             o = wya * (wxa * vaa + wxb * vab) + wyb * (wxa * vba + wxb * vbb);
         }
+        if (TERMS == 2) gm = sb_guard_max(gm, o);
         sb_split_dev<TERMS>(o, t[q]);
     }
+    if (TERMS == 2) sb_guard_flush(gm, ovf);
     unsigned short* d = out + (((n * C16 + c16) * HWo + p) * TERMS) * 16 + half * 8;
 #pragma unroll
     for (int kk = 0; kk < TERMS; ++kk) {
@@ -226,10 +230,11 @@ __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* 
         *reinterpret_cast<uint4*>(d + kk * 16) = v;
     }
 }
-static int upsample2x_sum_split(const float* a, const float* b, void* out_sb, int N, int C, int Hs, int Ws, int terms, hipStream_t s) {
+static int upsample2x_sum_split(const float* a, const float* b, void* out_sb, int N, int C, int Hs, int Ws, int terms, unsigned* ovf,
+                                hipStream_t s) {
     const dim3 grid((unsigned)cdivl(4L * Hs * Ws, 128), cdiv(C, 16), (unsigned)N);
-    if (terms == 2) hipLaunchKernelGGL(upsample2x_sum_split_kernel<2>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws);
-    else hipLaunchKernelGGL(upsample2x_sum_split_kernel<3>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws);
+    if (terms == 2) hipLaunchKernelGGL(upsample2x_sum_split_kernel<2>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws, ovf);
+    else hipLaunchKernelGGL(upsample2x_sum_split_kernel<3>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws, ovf);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
@@ -692,6 +697,7 @@ struct Workspace {
     std::vector<float*> hsb, ghb; // per level: hidden state as SB16, two buffers [2][2 dirs][B][C16][hw] / h-part of the gates [2][B][4C][hw]
     long sb_bytes = 0;
     hipGraphExec_t graph_exec = nullptr;   // captured launch sequence of forward_body for this shape
+    int graph_part = 0;                    // ... PART_ALL, or PART_MAIN when the forward's tail is launched behind the graph
     bool warm = false;
     void release() {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -780,6 +786,24 @@ struct bde_model {
     int lstm_fuse_x = 1;          // ... and the x-part of the gates in the same contraction (no batched gate convolution, no gx round trip)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
     long fused_min_tiles = 160;   // token_fused.h is used when a level has at least this many 32-pixel tiles
+    // ---- range guard of the two-term operand format (split.h) ----------------------------------------------------------------
+    // Every kernel that splits fp32 activations into two fp16 terms ORs bit 0 into the overflow word of the workspace slot its
+    // forward runs in when a value reaches 65520 (fp16's infinity).  The word is copied to pinned host memory behind the last
+    // such kernel; settle_overflow() reads it when the frames are handed over: "sb_auto" = 1 (default) recomputes the forward in
+    // the three-term bf16 format (fp32's exponent range) and keeps that format for the model, 0 fails with BDE_ERR_RANGE.
+    unsigned* ovf_dev = nullptr;  // [MAX_SLOTS] device words
+    unsigned* ovf_host = nullptr; // [MAX_SLOTS] pinned host mirror
+    int sb_auto = 1;
+    long sb_overflows = 0;        // forwards whose two-term operands left fp16's range
+    int sb_latched = 0;           // 1: such a forward switched the model to three bf16 terms
+    struct Pending {              // a forward whose overflow word has not been looked at yet
+        bool on = false;
+        hipEvent_t done = nullptr;
+        hipStream_t stream = nullptr;
+        int T = 0, B = 0, H = 0, W = 0;
+        std::vector<float*> images;
+    } pend[MAX_SLOTS];
+    unsigned* ovf() const { return (ovf_dev && sb_terms == 2) ? ovf_dev + cur : nullptr; }
     bool prof_on = false;
     struct ProfSpan { std::string name; hipEvent_t a, b; };
     std::vector<ProfSpan> prof;
@@ -1215,6 +1239,12 @@ static int upload(bde_model* m) {
     std::vector<float>().swap(m->arena.host);
     m->raw.clear();
     m->finalized = true;
+    if (!m->ovf_dev) {                      // overflow words of the range guard (split.h), one per workspace slot
+        BDE_HIP(hipMalloc((void**)&m->ovf_dev, sizeof(unsigned) * bde_model::MAX_SLOTS));
+        BDE_HIP(hipMemset(m->ovf_dev, 0, sizeof(unsigned) * bde_model::MAX_SLOTS));
+        BDE_HIP(hipHostMalloc((void**)&m->ovf_host, sizeof(unsigned) * bde_model::MAX_SLOTS, hipHostMallocDefault));
+        for (int i = 0; i < bde_model::MAX_SLOTS; ++i) m->ovf_host[i] = 0;
+    }
     return BDE_OK;
 }
 
@@ -1288,6 +1318,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         a.sb_out = reinterpret_cast<unsigned short*>(cc.out_sb);
         a.sb_out_ns = (long)cdiv(pl.Cout, 16) * a.Ho * a.Wo * (16 * m->sb_terms);
         a.sb_out_gs = cc.out_sb_gs * 2;
+        a.sb_ovf = m->ovf();
     }
     a.sb_terms = m->sb_terms;
     if (cc.pred_out) {
@@ -1310,7 +1341,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
         const long frames = (grouped_in ? pl.G : 1) * (long)cc.N;
         const long need = split_bf16_bytes(frames, pl.Cin, (long)cc.Hs * cc.Ws);
         if (cc.in_sb || (ws.sb && need <= ws.sb_bytes)) {
-            if (!cc.in_sb) BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, m->sb_terms, s));
+            if (!cc.in_sb) BDE_TRY(split_bf16(cc.in, ws.sb, frames, pl.Cin, (long)cc.Hs * cc.Ws, m->sb_terms, m->ovf(), s));
             ConvArgs b = a;
             b.in = cc.in_sb ? cc.in : ws.sb;
             b.wpk = m->P(pl.split_off(m->sb_terms));
@@ -2009,6 +2040,7 @@ static int run_attention_frame_win(bde_model* m, int l, const float* const* fram
             a.wfc1S = reinterpret_cast<const unsigned short*>(m->P(two ? ab.fc1H : ab.fc1S));
             a.wfc2S = reinterpret_cast<const unsigned short*>(m->P(two ? ab.fc2H : ab.fc2S));
             a.unscale = m->P(ab.unscaleH);
+            a.ovf = m->ovf();
         }
         a.stamps = m->tok_stamps;
         a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw; a.pt = ph / 2; a.pl = pw / 2;
@@ -2052,6 +2084,7 @@ static int run_tokgemm(bde_model* m, const char* span, int l, long w_off, const 
     if (wH_off >= 0 && m->wide_kv_sb && m->sb_terms == 2 && row_off == 0) {      // two fp16 terms on the matrix cores (tokgemm_sb_kernel)
         a.wS = reinterpret_cast<const unsigned short*>(m->P(wH_off));
         a.w_unscale = m->P(wH_unscale);
+        a.ovf = m->ovf();
         if (tokgemm_sb_fits(a)) return tokgemm_sb_launch(a, B, s);
     }
     return tokgemm_launch(a, B, s);
@@ -2095,6 +2128,7 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
             if (m->wide_kv_sb && m->sb_terms == 2 && ab.qkvHF >= 0) {          // q|k|v on two fp16 terms (wideblock.h)
                 a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(ab.qkvHF));
                 a.wqkv_unscale = m->P(ab.qkvHF_unscale);
+                a.ovf = m->ovf();
             }
         }
         a.q = qkv;
@@ -2135,6 +2169,7 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
             pa.hid_bs = (long)ntile * 16 * 4 * C;
             pa.C = C; pa.hidden = 4 * C; pa.HW = (int)HW; pa.ntile = ntile;
             pa.mask_w = dil ? W : 0; pa.mask_pt = pt; pa.mask_pl = plft;
+            pa.ovf = m->ovf();
             ProfScope ps(m, pname("wide_projfc", l), s);
             BDE_TRY(projfc1_sb_launch(pa, B, s));
         } else {
@@ -2283,18 +2318,24 @@ static int run_bottleneck_level(bde_model* m, int l, int T, int B, int h, int w,
     return BDE_OK;
 }
 
+// Parts of a forward (forward_on): PART_MAIN = everything up to and including the last kernel that writes split operands,
+// PART_TAIL = what follows it -- the last decoder's convolution (+ predI).  The overflow word of the range guard (split.h) is
+// read back between the two, so the host learns about an overflow while the tail still runs.
+enum { PART_ALL = 0, PART_MAIN = 1, PART_TAIL = 2 };
+
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
-                       hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr) {
+                       hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr, int part = PART_ALL) {
     const PackedLayer& pl = m->dec[j];
     Workspace& ws = m->W();
     // a split-bf16 convolution reads SB16: the upsampling kernel then writes that image directly (no fp32 map, no conversion)
     const bool to_sb = m->fuse_enc_sb && (!pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, 1, N, 2 * Hs, 2 * Ws) && ws.sb &&
                        split_bf16_bytes(N, pl.Cin, 4L * Hs * Ws) <= ws.sb_bytes;
-    {
+    if (part != PART_TAIL) {
         ProfScope ps(m, pname("dec_up", j), s);
-        if (to_sb) BDE_TRY(upsample2x_sum_split(in, skip, ws.sb, N, pl.Cin, Hs, Ws, m->sb_terms, s));
+        if (to_sb) BDE_TRY(upsample2x_sum_split(in, skip, ws.sb, N, pl.Cin, Hs, Ws, m->sb_terms, m->ovf(), s));
         else BDE_TRY(upsample2x_sum(in, skip, ws.up, Hs, Ws, (long)N * pl.Cin, s));
     }
+    if (part == PART_MAIN) return BDE_OK;
     ConvCall d;
     d.pl = &pl;
     d.in = to_sb ? ws.sb : ws.up;
@@ -2340,16 +2381,94 @@ static int pipeline_stream(int slot, hipStream_t* out) {
     return BDE_OK;
 }
 
+// ---- range guard of the two-term operand format: host side (split.h; bde_model::ovf_dev) ---------------------------------------
+// Copy the current slot's overflow word to its pinned mirror and mark the point with the slot's event (forward_on).
+static int note_overflow_readback(bde_model* m, hipStream_t s) {
+    bde_model::Pending& p = m->pend[m->cur];
+    if (!p.done) BDE_HIP(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    BDE_HIP(hipMemcpyAsync(m->ovf_host + m->cur, m->ovf_dev + m->cur, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    BDE_HIP(hipEventRecord(p.done, s));
+    return BDE_OK;
+}
+// Remember what a forward needs to be recomputed: its stream, shape and output pointers (its events stay in the workspace).
+static void note_pending(bde_model* m, int slot, hipStream_t s, int T, int B, int H, int W, float* const* images) {
+    bde_model::Pending& p = m->pend[slot];
+    p.on = true; p.stream = s; p.T = T; p.B = B; p.H = H; p.W = W;
+    p.images.assign(images, images + T);
+}
+// Look at the overflow words of all forwards issued so far (waits for them).  None set: nothing to do.  Otherwise, "sb_auto" = 1:
+// the model switches to three bf16 terms for good and the forwards that overflowed are recomputed from the events their
+// workspaces still hold, into the same output buffers, on the streams they ran on; "sb_auto" = 0: BDE_ERR_RANGE.
+static int settle_overflow(bde_model* m) {
+    bool flagged[bde_model::MAX_SLOTS] = {};
+    int nflag = 0;
+    for (int i = 0; i < bde_model::MAX_SLOTS; ++i) {
+        bde_model::Pending& p = m->pend[i];
+        if (!p.on) continue;
+        BDE_HIP(hipEventSynchronize(p.done));
+        if (m->ovf_host[i] != 0) { flagged[i] = true; ++nflag; }
+    }
+    if (nflag == 0) {
+        for (auto& p : m->pend) p.on = false;
+        return BDE_OK;
+    }
+    m->sb_overflows += nflag;
+    for (int i = 0; i < bde_model::MAX_SLOTS; ++i) m->ovf_host[i] = 0;
+    if (!m->sb_auto) {
+        for (auto& p : m->pend) p.on = false;
+        return fail(BDE_ERR_RANGE, "%d forward(s): an activation reached 65520, beyond the two fp16 terms of the default operand format "
+                    "(csrc/split.h); the frames of those calls are not valid.  set_tuning(\"sb_terms\", 3) or \"sb_auto\" = 1", nflag);
+    }
+    // every forward issued so far has to be complete before the workspaces go (the switch of formats releases them)
+    for (int i = 0; i < bde_model::MAX_SLOTS; ++i)
+        if (m->pend[i].on) BDE_HIP(hipStreamSynchronize(m->pend[i].stream));
+    struct Redo { int slot; float* ev; long ev_fs; };
+    std::vector<Redo> redo;
+    for (int i = 0; i < bde_model::MAX_SLOTS; ++i) {
+        if (!flagged[i]) continue;
+        const bde_model::Pending& p = m->pend[i];
+        const long ev_fs = (long)p.B * m->cfg.num_bins * p.H * p.W;
+        float* ev = nullptr;
+        BDE_HIP(hipMalloc((void**)&ev, sizeof(float) * ev_fs * p.T));
+        BDE_HIP(hipMemcpy(ev, m->wslots[i].ev, sizeof(float) * ev_fs * p.T, hipMemcpyDeviceToDevice));
+        redo.push_back({i, ev, ev_fs});
+    }
+    for (auto& w : m->wslots) w.release();
+    m->sb_terms = 3;
+    m->sb_latched = 1;
+    int st = BDE_OK;
+    for (const Redo& r : redo) {
+        bde_model::Pending p = m->pend[r.slot];
+        std::vector<const float*> evp(p.T);
+        for (int t = 0; t < p.T; ++t) evp[t] = r.ev + (long)t * r.ev_fs;
+        m->cur = r.slot;
+        if (st == BDE_OK) st = forward_on(m, evp.data(), p.T, p.B, p.H, p.W, p.images.data(), p.stream);
+        (void)hipStreamSynchronize(p.stream);
+        (void)hipFree(r.ev);
+    }
+    m->cur = 0;
+    for (auto& p : m->pend) p.on = false;
+    return st;
+}
+
 // Pipelined dispatch: call i runs on internal stream i%depth with workspace i%depth.  Inputs are ordered
 // after the caller's stream by an event; outputs are ordered back by bde_wait_outputs (or by the
 // next call that reuses the slot).
 static int forward_impl(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
                         hipStream_t user) {
     if (m->pipeline < 2) {
+        // (a forward still pending here was issued in pipelined mode: look at it before its slot's word is reused)
+        for (const auto& p : m->pend) if (p.on) { BDE_TRY(settle_overflow(m)); break; }
         m->cur = 0;
-        return forward_on(m, events, T, B, H, W, images, user);
+        BDE_TRY(forward_on(m, events, T, B, H, W, images, user));
+        if (m->ovf() == nullptr) return BDE_OK;
+        // default mode: the frames are final when this call returns, so the overflow word is looked at here -- the host waits
+        // for the forward up to its last operand split while the tail (the last convolution) is still running
+        note_pending(m, 0, user, T, B, H, W, images);
+        return settle_overflow(m);
     }
     const int slot = (int)(m->ncalls++ % m->pipeline);
+    if (m->pend[slot].on) BDE_TRY(settle_overflow(m));       // the slot's previous forward must be final before its workspace is reused
     if (!m->pstream[slot]) {
         BDE_TRY(pipeline_stream(slot, &m->pstream[slot]));
         BDE_HIP(hipEventCreateWithFlags(&m->pin[slot], hipEventDisableTiming));
@@ -2360,6 +2479,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
     BDE_HIP(hipStreamWaitEvent(m->pstream[slot], m->pin[slot], 0));
     m->last_stream = m->pstream[slot];
     const int st = forward_on(m, events, T, B, H, W, images, m->pstream[slot]);
+    if (st == BDE_OK && m->ovf() != nullptr) note_pending(m, slot, m->pstream[slot], T, B, H, W, images);
     BDE_HIP(hipEventRecord(m->pout[slot], m->pstream[slot]));
     m->pbusy[slot] = true;
     m->cur = 0;
@@ -2369,7 +2489,7 @@ static int forward_impl(bde_model* m, const float* const* events, int T, int B, 
 // Everything between the input copy and the output copy: pointers depend only on the workspace,
 // so the launch sequence can be captured once per (slot, T, B, H, W) into a hipGraph and replayed
 // (~630 launches per forward at config A; replay removes their host cost).
-static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s);
+static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s, int part);
 
 static int forward_on(bde_model* m, const float* const* events, int T, int B, int H, int W, float* const* images,
                       hipStream_t s) {
@@ -2378,14 +2498,25 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
     Workspace& ws = m->W();
     const long ev_fs = (long)B * m->cfg.num_bins * H * W, img_fs = (long)B * H * W;
     BDE_TRY(copy_frames(events, ws.ev, T, ev_fs, 0, s));
-    const bool can_graph = m->use_graph && !(m->overlap && m->pipeline < 2) && ws.warm;   // (profiling spans are captured as event-record nodes)
+    ProfScope whole(m, "forward", s);
+    // Range guard (split.h): the slot's overflow word starts at zero and is read back behind the last kernel that writes split
+    // operands -- in front of the forward's tail where the tail is a launch of its own (no side-stream decode, the upsampling
+    // kernel writes the last convolution's operand image itself), behind it otherwise.
+    const bool guard = m->ovf() != nullptr;
+    const bool side_decode = m->overlap != 0 && m->pipeline < 2;
+    const bool cut = guard && !side_decode && m->fuse_enc_sb && !(m->debug_skip & 8);
+    const int part_main = cut ? PART_MAIN : PART_ALL;
+    if (guard) BDE_HIP(hipMemsetAsync(m->ovf(), 0, sizeof(unsigned), s));
+    const bool can_graph = m->use_graph && !side_decode && ws.warm;   // (profiling spans are captured as event-record nodes)
+    if (ws.graph_exec && ws.graph_part != part_main) { (void)hipGraphExecDestroy(ws.graph_exec); ws.graph_exec = nullptr; }
     if (can_graph && !ws.graph_exec) {
         // capture on a private stream (the caller's may be the legacy default stream, which cannot
         // capture); the instantiated graph is then launched on the caller's stream
         if (!m->cap_stream) BDE_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
         hipGraph_t graph = nullptr;
         BDE_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
-        const int st = forward_body(m, T, B, H, W, m->cap_stream);
+        const int st = forward_body(m, T, B, H, W, m->cap_stream, part_main);
+        ws.graph_part = part_main;
         const hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
         hipError_t ei = hipSuccess;
         if (st == BDE_OK && e == hipSuccess) ei = hipGraphInstantiate(&ws.graph_exec, graph, nullptr, nullptr, 0);
@@ -2400,15 +2531,18 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
     if (m->use_graph && can_graph && ws.graph_exec) {
         BDE_HIP(hipGraphLaunch(ws.graph_exec, s));
     } else {
-        BDE_TRY(forward_body(m, T, B, H, W, s));
+        BDE_TRY(forward_body(m, T, B, H, W, s, part_main));
         ws.warm = true;                       // first call of a shape runs eagerly (one-time kernel attribute setup)
     }
+    if (guard && cut) BDE_TRY(note_overflow_readback(m, s));
+    if (cut) BDE_TRY(forward_body(m, T, B, H, W, s, PART_TAIL));     // one or two launches: not worth a graph of their own
+    if (guard && !cut) BDE_TRY(note_overflow_readback(m, s));
     BDE_TRY(copy_frames(images, ws.out, T, img_fs, 1, s));
     return BDE_OK;
 }
 
 // C. decoder for frames [f0, f0 + nf) of the [T*B] stack (V5.py:183-197)
-static int decode_frames(bde_model* mm, int f0, int nf, int T_, int B_, int H_, int W_, hipStream_t st) {
+static int decode_frames(bde_model* mm, int f0, int nf, int T_, int B_, int H_, int W_, hipStream_t st, int part = PART_ALL) {
     // C. decoder (V5.py:183-197): x = L[-1]; x = dec_j(L[-1-j] + x); img = act(predI(x + head))
     Workspace& w = mm->W();
     const int L_ = mm->L;
@@ -2417,20 +2551,27 @@ static int decode_frames(bde_model* mm, int f0, int nf, int T_, int B_, int H_, 
         const int l = L_ - 1 - j;
         const long in_fs = (long)mm->cout(l) * (H_ >> (l + 1)) * (W_ >> (l + 1));
         const long out_fs = (long)mm->cin(l) * (H_ >> l) * (W_ >> l);
-        ProfScope ps(mm, "decoder", st);
-        const bool fuse = (j == L_ - 1) && pred_fusable(mm);       // V5.py:195-197 in the last conv's epilogue
-        const float* skip = w.merged[l] + (long)f0 * in_fs;
-        if (mm->cfg.skip_concat) {                                 // decoder = Sequential(1x1 fusion, UpsampleConvLayer)
-            BDE_TRY(run_concat_fuse(mm, mm->dec_fuse[j], skip, x, nf, mm->cout(l), (long)(H_ >> (l + 1)) * (W_ >> (l + 1)), st));
-            x = w.fuse;
-            skip = nullptr;
+        // the tail of a forward = the last decoder's convolution: PART_MAIN stops in front of it, PART_TAIL runs nothing else
+        const bool lastj = j == L_ - 1;
+        const int jpart = part == PART_ALL ? PART_ALL : (lastj ? part : (part == PART_MAIN ? PART_ALL : -1));
+        if (jpart >= 0) {
+            ProfScope ps(mm, "decoder", st);
+            const bool fuse = lastj && pred_fusable(mm);               // V5.py:195-197 in the last conv's epilogue
+            const float* skip = w.merged[l] + (long)f0 * in_fs;
+            if (mm->cfg.skip_concat) {                                 // decoder = Sequential(1x1 fusion, UpsampleConvLayer)
+                if (jpart != PART_TAIL)
+                    BDE_TRY(run_concat_fuse(mm, mm->dec_fuse[j], skip, x, nf, mm->cout(l), (long)(H_ >> (l + 1)) * (W_ >> (l + 1)), st));
+                x = w.fuse;
+                skip = nullptr;
+            }
+            BDE_TRY(run_decoder(mm, j, x, skip, w.dec[j] + (long)f0 * out_fs, nf,
+                                H_ >> (l + 1), W_ >> (l + 1), st,
+                                fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
+                                fuse ? w.out + (long)f0 * H_ * W_ : nullptr, jpart));
         }
-        BDE_TRY(run_decoder(mm, j, x, skip, w.dec[j] + (long)f0 * out_fs, nf,
-                            H_ >> (l + 1), W_ >> (l + 1), st,
-                            fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
-                            fuse ? w.out + (long)f0 * H_ * W_ : nullptr));
         x = w.dec[j] + (long)f0 * out_fs;
     }
+    if (part == PART_MAIN) return BDE_OK;
     if (pred_fusable(mm)) return BDE_OK;
     const long total = (long)nf * H_ * W_;
     long blocks = std::min<long>(cdivl(total, 256), 4096);
@@ -2449,12 +2590,12 @@ static int decode_frames(bde_model* mm, int f0, int nf, int T_, int B_, int H_, 
     return BDE_OK;
 }
 
-static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s) {
-    ProfScope whole(m, "forward", s);
+static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s, int part) {
     const bde_config& c = m->cfg;
     Workspace& ws = m->W();
     const int L = c.num_encoders;
     const long TB = (long)T * B;
+    if (part == PART_TAIL) return (m->debug_skip & 8) ? BDE_OK : decode_frames(m, 0, (int)TB, T, B, H, W, s, PART_TAIL);
     // A. head (V5.py:116)
     ConvCall hc;
     hc.pl = &m->head;
@@ -2505,7 +2646,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
                     const int t0 = (done - 1) / q->chunk * q->chunk, nt = done - t0;
                     BDE_HIP(hipEventRecord(mm->frame_ev[t], q->main));
                     BDE_HIP(hipStreamWaitEvent(q->side, mm->frame_ev[t], 0));
-                    if (q->last) return decode_fn(mm, t0 * q->B, nt * q->B, q->T, q->B, q->H, q->W, q->side);
+                    if (q->last) return decode_fn(mm, t0 * q->B, nt * q->B, q->T, q->B, q->H, q->W, q->side, PART_ALL);
                     const int ln = q->l + 1;
                     return run_enc_gx(mm, ln, mm->W().merged[q->l], t0 * q->B, nt * q->B, q->T, q->B, q->H >> ln, q->W >> ln, q->side);
                 };
@@ -2520,7 +2661,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s)
         if (l == L - 1 && c.depths[l] == 0) BDE_TRY(run_bottleneck_level(m, l, T, B, h, w, s));
         target = ws.merged[l];
     }
-    if (!decoded && !(m->debug_skip & 8)) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s));
+    if (!decoded && !(m->debug_skip & 8)) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s, part));
     return BDE_OK;
 }
 
@@ -2559,7 +2700,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 const char* bde_last_error(void) { return last_error_ref().c_str(); }
-int bde_abi_version(void) { return 3; }   // 3: bde_debug_split, operand-format keys, packed image holds both split packings
+int bde_abi_version(void) { return 4; }   // 4: BDE_ERR_RANGE, "sb_auto" and the range guard of the two-term format; bde_wait_outputs may recompute
 
 int bde_create(const bde_config* cfg, bde_model** out) {
     BDE_REQUIRE(out != nullptr, "null out");
@@ -2587,6 +2728,9 @@ void bde_destroy(bde_model* m) {
         // (pstream[i] belongs to the per-device pool, pipeline_stream())
     }
     if (m->dev) (void)hipFree(m->dev);
+    if (m->ovf_dev) (void)hipFree(m->ovf_dev);
+    if (m->ovf_host) (void)hipHostFree(m->ovf_host);
+    for (auto& p : m->pend) if (p.done) (void)hipEventDestroy(p.done);
     for (int i = 0; i < 4; ++i) {
         if (m->dir_fork[i]) (void)hipEventDestroy(m->dir_fork[i]);
         if (m->dir_join[i]) (void)hipEventDestroy(m->dir_join[i]);
@@ -2724,6 +2868,7 @@ int bde_split_begin(bde_model* m, const float* const* events, int32_t T, int32_t
     BDE_TRY(ensure_workspace(m, T, B, Hp, Wp));
     Workspace& ws = m->W();
     BDE_TRY(copy_frames(events, ws.ev, T, (long)B * m->cfg.num_bins * Hp * Wp, 0, s));
+    if (m->ovf()) BDE_HIP(hipMemsetAsync(m->ovf(), 0, sizeof(unsigned), s));      // range guard (split.h): checked by bde_split_decode
     ConvCall hc;
     hc.pl = &m->head; hc.in = ws.ev; hc.out = ws.head; hc.N = T * B; hc.Hs = Hp; hc.Ws = Wp; hc.act = ACT_RELU;
     return run_conv(m, hc, s);
@@ -2768,7 +2913,23 @@ int bde_split_decode(bde_model* m, float* const* images, void* stream) {
     BDE_TRY(split_dims(m, &T, &B, &H, &W));
     for (int t = 0; t < T; ++t) BDE_REQUIRE(images[t], "null frame pointer at t=%d", t);
     BDE_TRY(decode_frames(m, 0, T * B, T, B, H, W, s));
-    return copy_frames(images, m->W().out, T, (long)B * H * W, 1, s);
+    BDE_TRY(copy_frames(images, m->W().out, T, (long)B * H * W, 1, s));
+    if (m->ovf()) {
+        // range guard of the two-term operand format (split.h): no automatic recomputation here -- the two ranks of a split
+        // forward would have to switch formats together (dist.DirectionSplit does that through "sb_overflow_word")
+        unsigned v = 0;
+        BDE_HIP(hipMemcpyAsync(m->ovf_host, m->ovf(), sizeof v, hipMemcpyDeviceToHost, s));
+        BDE_HIP(hipStreamSynchronize(s));
+        v = m->ovf_host[0];
+        m->ovf_host[0] = 0;
+        if (v) {
+            BDE_HIP(hipMemset(m->ovf(), 0, sizeof v));
+            ++m->sb_overflows;
+            return fail(BDE_ERR_RANGE, "split forward: an activation reached 65520, beyond the two fp16 terms of the default operand "
+                        "format (csrc/split.h); set_tuning(\"sb_terms\", 3) on both ranks and run it again");
+        }
+    }
+    return BDE_OK;
 }
 
 int bde_split_buffer(bde_model* m, const char* what, int32_t level, int32_t direction, float** ptr, int64_t* numel) {
@@ -2793,12 +2954,16 @@ int bde_split_buffer(bde_model* m, const char* what, int32_t level, int32_t dire
 
 int bde_wait_outputs(bde_model* m, void* stream) {
     BDE_REQUIRE(m != nullptr, "null model");
+    TuningScope ts(&m->tune);
+    // range guard (split.h): forwards whose operands left fp16's range are recomputed here (or fail the call) -- on their own
+    // streams, i.e. still ahead of the events `stream` is about to wait for
+    const int st = settle_overflow(m);
     for (int i = 0; i < bde_model::MAX_SLOTS; ++i)
         if (m->pbusy[i]) {
             BDE_HIP(hipStreamWaitEvent((hipStream_t)stream, m->pout[i], 0));
             m->pbusy[i] = false;
         }
-    return BDE_OK;
+    return st;
 }
 
 int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
@@ -2808,6 +2973,15 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         BDE_REQUIRE(value >= 1 && value <= bde_model::MAX_SLOTS, "pipeline depth must be 1..%d", bde_model::MAX_SLOTS);
         m->pipeline = (int)value;
         return BDE_OK;
+    }
+    if (std::string(key) == "sb_auto") {
+        BDE_REQUIRE(value == 0 || value == 1, "sb_auto: 0 (an overflow of the two-term format fails the call) or 1 (recompute with three terms)");
+        m->sb_auto = (int)value;
+        return BDE_OK;
+    }
+    {   // forwards still in flight keep their events in the workspaces: look at their overflow words before anything is released
+        TuningScope ts(&m->tune);
+        for (const auto& p : m->pend) if (p.on) { BDE_TRY(settle_overflow(m)); break; }
     }
     for (auto& w : m->wslots)
         if (w.graph_exec) { (void)hipGraphExecDestroy(w.graph_exec); w.graph_exec = nullptr; }
@@ -2840,6 +3014,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         if (m->sb_terms != (int)value)
             for (auto& w : m->wslots) w.release();           // launch shapes and buffer roles depend on the format
         m->sb_terms = (int)value;
+        m->sb_latched = 0;
         return BDE_OK;
     }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
@@ -2900,6 +3075,18 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "wide_kv_sb") *value = m->wide_kv_sb;
     else if (k == "wide_fuse_mlp") *value = m->wide_fuse_mlp;
     else if (k == "sb_terms") *value = m->sb_terms;
+    else if (k == "sb_auto") *value = m->sb_auto;
+    else if (k == "sb_overflows") *value = m->sb_overflows;       // forwards settled so far whose two-term operands left fp16's range
+    else if (k == "sb_latched") *value = m->sb_latched;           // 1: such a forward switched the model to three bf16 terms
+    else if (k == "sb_overflow_word") {                           // the overflow word of slot 0 as it stands (op-level entry points
+        unsigned v = 0;                                           //  and bde_split_sweep raise it without anybody settling it);
+        if (m->ovf_dev) {                                         //  reading clears it
+            BDE_HIP(hipDeviceSynchronize());
+            BDE_HIP(hipMemcpy(&v, m->ovf_dev, sizeof v, hipMemcpyDeviceToHost));
+            BDE_HIP(hipMemset(m->ovf_dev, 0, sizeof v));
+        }
+        *value = v;
+    }
     else if (k == "packed_numel") *value = m->dev_numel;
     else if (k == "sb_head") *value = m->head.sb_used;
     else if (k.compare(0, 3, "sb_") == 0 && k.size() >= 5 && k.back() >= '0' && k.back() - '0' < m->L) {

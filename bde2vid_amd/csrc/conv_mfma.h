@@ -83,6 +83,7 @@ struct ConvArgs {
     // the power-of-two scale the two-term weights were packed with (it lives in the packed image beside them)
     int sb_terms;
     const float* acc_scale;
+    unsigned* sb_ovf;            // range guard of the two-term format (split.h): the forward's overflow word, written by sb_out stores
     int xcd_remap;               // conv_sb.h: workgroup order that keeps neighbouring tiles in one XCD's L2
     // one sweep direction per GPU (bde_split_*): the launch covers `groups` of the layer's groups, but every launch-shape
     // choice is made as if all `decide_groups` were present, so each direction computes exactly what the joint launch computes
@@ -189,6 +190,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
         // a lane's registers 4q .. 4q+3 are four consecutive output channels (acc_row): 8 bytes of each of the three terms
         static_assert(RPW % 4 == 0, "split-bf16 store takes registers in groups of four");
         unsigned short* sbb = a.sb_out + g * a.sb_out_gs + n * a.sb_out_ns;
+        float gm = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int p = pix[t];
@@ -209,6 +211,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
                     if (a.sb_terms == 2) {
                         unsigned short* d = sbb + ((long)(co0 >> 4) * HW + p) * 32 + (co0 & 15);
                         uint2 hi, lo;
+                        gm = sb_guard_max2(sb_guard_max2(gm, v4[0], v4[1]), v4[2], v4[3]);
                         split2_quad(v4, hi, lo);
                         *reinterpret_cast<uint2*>(d) = hi;
                         *reinterpret_cast<uint2*>(d + 16) = lo;
@@ -222,6 +225,7 @@ __device__ __forceinline__ void generic_epilogue(const ConvArgs& a, const float 
                     }
                 }
         }
+        if (a.sb_terms == 2) sb_guard_flush(gm, a.sb_ovf);
         return;
     }
 #pragma unroll

@@ -29,7 +29,8 @@ namespace bde {
 // fp32 [N][C][H][W] -> SB16 [N][C16][H][W][terms][16].  grid (ceil(HW / 128), C16, N), 256 threads: thread = (pixel, half of
 // the chunk), a wave = 64 consecutive pixels of one half: 8 plane loads of 256 contiguous bytes each, one 16-byte store per term.
 template <int TERMS>
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, long HW) {
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, long HW,
+                                                         unsigned* ovf) {
     const int half = threadIdx.x >> 7;
     const long p = (long)blockIdx.x * 128 + (threadIdx.x & 127);
     const int c16 = blockIdx.y;
@@ -37,12 +38,15 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     if (p >= HW) return;
     const int C16 = gridDim.y;
     unsigned short t[8][TERMS];
+    float gm = 0.f;                                        // range guard of the two-term format (split.h)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c16 * 16 + half * 8 + j;
         const float x = c < C ? in[(n * C + c) * HW + p] : 0.f;
+        if (TERMS == 2) gm = sb_guard_max(gm, x);
         sb_split_dev<TERMS>(x, t[j]);
     }
+    if (TERMS == 2) sb_guard_flush(gm, ovf);
     unsigned short* o = out + (((n * C16 + c16) * HW + p) * TERMS) * 16 + half * 8;
 #pragma unroll
     for (int k = 0; k < TERMS; ++k) {
@@ -54,20 +58,20 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         *reinterpret_cast<uint4*>(o + k * 16) = v;
     }
 }
-int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, hipStream_t s) {
+int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, unsigned* ovf, hipStream_t s) {
     const int C16 = cdiv(C, 16);
     const dim3 grid((unsigned)cdivl(HW, 128), C16, (unsigned)N);
-    if (terms == 2) hipLaunchKernelGGL(split_bf16_kernel<2>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, HW);
-    else hipLaunchKernelGGL(split_bf16_kernel<3>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, HW);
+    if (terms == 2) hipLaunchKernelGGL(split_bf16_kernel<2>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, HW, ovf);
+    else hipLaunchKernelGGL(split_bf16_kernel<3>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, HW, ovf);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
 #else
-int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, hipStream_t s);   // sb_tu.hip
+int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, unsigned* ovf, hipStream_t s);   // sb_tu.hip
 #endif
 // ConvLSTM pointwise tail for the split-bf16 recurrent step (submodules.py:320-332): gates = gx (x-part incl. bias) + gh
 // (h-part, from conv_sb_kernel; nullptr at the first step, h = 0), chunk order i, f, o, g; c = sigma(f) c + sigma(i) tanh(g);
-// h = sigma(o) tanh(c).  Writes c in place, h as fp32 planes (the level's hidden sequence) and as SB16 (the next step's
+// h = sigma(o) tanh(c) -- |h| < 1, so this producer of an SB16 image needs no range guard (split.h).  Writes c in place, h as fp32 planes (the level's hidden sequence) and as SB16 (the next step's
 // convolution input).  grid (ceil(HW / 128), C16, 2 * B), thread = (pixel, half of a 16-channel chunk).
 struct LstmPointArgs {
     const float* gx;       // direction g, frame n: gx + g * gx_gs + n * gx_ns, [4C][HW]
@@ -287,8 +291,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             // so the counted wait covers them and leaves the fragment ring in flight.  A bare s_barrier follows
             // (__syncthreads() would drain vmcnt to 0 and the ring with it); LDS reads of the other buffer were waited
             // for by the MFMAs that consumed them.
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TERMS * PF * MT) : "memory");
-            __builtin_amdgcn_s_barrier();
+            // (the barrier as asm with a memory clobber: the intrinsic is IntrNoMem, LDS reads or the next stage's DMA may not cross it)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TERMS * PF * MT) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -96,7 +96,23 @@ static inline float sb_weight_scale(const float* w, long n) {
     return __builtin_bit_cast(float, (unsigned)(127 + sh) << 23);
 }
 
+// Largest finite fp32 magnitude the two-term format carries: anything at or above it rounds to the fp16 infinity.
+constexpr float SB_F16_LIMIT = 65520.f;
+
 #if defined(__HIPCC__)
+// ---- range guard of the two-term format -------------------------------------------------------------------------------------------
+// Every kernel that turns fp32 activations into two fp16 terms keeps the running maximum of |x| over the values it splits (one
+// v_max_f32 / half a v_max3_f32 per value: the |.| is an operand modifier) and, should that maximum reach SB_F16_LIMIT, ORs bit 0
+// into the forward's overflow word.  The host reads the word when the forward's frames are handed over (bde_api.hip,
+// resolve_overflow): the frames of a forward that set it are recomputed in the three-term bf16 format, which has fp32's
+// exponent range ("sb_auto", default), or the call fails with BDE_ERR_RANGE.  A NaN does not raise the flag (max drops it) and
+// travels through either format as a NaN; an infinite input does (three bf16 terms carry it exactly as fp32 does).
+__device__ __forceinline__ float sb_guard_max(float gm, float x) { return fmaxf(gm, fabsf(x)); }
+__device__ __forceinline__ float sb_guard_max2(float gm, float x0, float x1) { return fmaxf(fmaxf(gm, fabsf(x0)), fabsf(x1)); }
+__device__ __forceinline__ void sb_guard_flush(float gm, unsigned* flag) {
+    if (flag != nullptr && gm >= SB_F16_LIMIT) atomicOr(flag, 1u);
+}
+
 // device-side splits on the conversion instructions
 __device__ __forceinline__ void split2_dev(float x, unsigned short& hi, unsigned short& lo) {
     const _Float16 h = (_Float16)x;

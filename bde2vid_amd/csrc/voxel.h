@@ -471,6 +471,16 @@ __global__ __launch_bounds__(1024) void voxel_tile_from_buckets_kernel(const Vox
         const int c0 = a & 0x1fffu;
         if (FIXED) {
             if (nan_window) { atomicAdd(tile64 + c0, 1ull); return; }
+            if (!(t == t)) {
+                // a NaN time stamp inside an ordinary window: max(0, 1 - |NaN - b|) is NaN in every bin of that pixel (:494-495,
+                // torch.max hands the NaN on), as on the streaming and the float paths.  Fixed point has no NaN: bits 62, 61 of
+                // the sum are forced to 0, 1 -- a pattern no sum of fewer than 2^28 weights reaches and no later add removes.
+                for (int b = 0; b < nb; ++b) {
+                    atomicOr(tile64 + c0 + b * tpx, 1ull << 61);
+                    atomicAnd(tile64 + c0 + b * tpx, ~(1ull << 62));
+                }
+                return;
+            }
         } else if (!(t == t)) {                                        // dt == 0 -> NaN weights in every bin (:494-495)
             for (int b = 0; b < nb; ++b) atomicAdd(tile + c0 + b * tpx, p * t);
             return;
@@ -545,7 +555,11 @@ __global__ __launch_bounds__(1024) void voxel_tile_from_buckets_kernel(const Vox
         float v;
         if (FIXED) {
             if (nan_window) v = tile64[ly * TW + lx] ? __builtin_nanf("") : 0.f;
-            else v = (float)((double)(long long)tile64[(b * TH + ly) * TW + lx] * 2.3283064365386963e-10);   // exact product, one rounding
+            else {
+                const long long q = (long long)tile64[(b * TH + ly) * TW + lx];
+                v = (q >= (1ll << 60) || q <= -(1ll << 60)) ? __builtin_nanf("")                            // marked by a NaN time stamp
+                                                            : (float)((double)q * 2.3283064365386963e-10);   // exact product, one rounding
+            }
         } else {
             v = tile[(b * TH + ly) * TW + lx];
         }
@@ -553,23 +567,35 @@ __global__ __launch_bounds__(1024) void voxel_tile_from_buckets_kernel(const Vox
     }
 }
 
-// scratch of the bucketed path (records + run tables), one buffer per device, grown on demand
-struct VoxelScratch { void* p = nullptr; size_t bytes = 0; };
-inline int voxel_scratch(size_t need, void** out) {
-    static VoxelScratch pool[BDE_MAX_DEVICES];
+// Scratch of the bucketed path (records + run tables): STREAM-ORDERED -- allocated on the caller's stream in front of the two
+// launches of a call and freed behind them (hipMallocAsync / hipFreeAsync), so calls on different streams or from different host
+// threads never share a buffer and nothing is freed under a launch that still reads it.  The device's default pool keeps freed
+// blocks (release threshold raised once per device): after the first call of a size an allocation is a pool hit.  A call whose
+// scratch would pass VB_SCRATCH_CAP, or whose allocation fails, gets *out = nullptr and takes the streaming kernel instead.
+constexpr size_t VB_SCRATCH_CAP = 8ull << 30;
+inline int voxel_scratch_acquire(size_t need, hipStream_t stream, void** out) {
+    static unsigned char pool_ready[BDE_MAX_DEVICES];
     static std::mutex mu;
+    *out = nullptr;
+    if (need > VB_SCRATCH_CAP) return BDE_OK;
     int d = 0;
     BDE_HIP(hipGetDevice(&d));
     if (d < 0 || d >= BDE_MAX_DEVICES) return fail(BDE_ERR_ARG, "device %d", d);
-    std::lock_guard<std::mutex> lock(mu);
-    VoxelScratch& s = pool[d];
-    if (s.bytes < need) {
-        if (s.p) { BDE_HIP(hipDeviceSynchronize()); BDE_HIP(hipFree(s.p)); s.p = nullptr; s.bytes = 0; }
-        const size_t sz = need + need / 4;
-        BDE_HIP(hipMalloc(&s.p, sz));
-        s.bytes = sz;
+    if (!__atomic_load_n(&pool_ready[d], __ATOMIC_ACQUIRE)) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!pool_ready[d]) {
+            hipMemPool_t pool = nullptr;
+            uint64_t keep = ~0ull;
+            if (hipDeviceGetDefaultMemPool(&pool, d) == hipSuccess && pool)
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            (void)hipGetLastError();
+            __atomic_store_n(&pool_ready[d], (unsigned char)1, __ATOMIC_RELEASE);
+        }
     }
-    *out = s.p;
+    if (hipMallocAsync(out, need, stream) != hipSuccess) {
+        (void)hipGetLastError();                        // out of memory: the caller streams instead
+        *out = nullptr;
+    }
     return BDE_OK;
 }
 
@@ -651,13 +677,23 @@ static inline int voxel_bucket_launch(const void* xs, const void* ys, const void
     const size_t lds = (size_t)CELL * nb * TH * TW;
     static unsigned char raised[BDE_MAX_DEVICES];
     BDE_HIP(raise_dynamic_lds(raised, (const void*)voxel_tile_from_buckets_kernel<NATIVE>, 144 * 1024));   // (+ 8.3 KB of static LDS)
+    // one scratch for the call, sized for its largest batch of windows (batches follow each other on the stream)
+    auto sizes = [&](int nw, size_t* rec_bytes, size_t* p_bytes, size_t* tab_bytes) {
+        const size_t nrec = (size_t)nw * nchunks * VB_CHUNK;
+        *rec_bytes = nrec * sizeof(VoxelRec);
+        *p_bytes = NATIVE ? 0 : nrec * sizeof(float);
+        *tab_bytes = (size_t)nw * nchunks * (ntiles + 1) * sizeof(int);
+    };
+    size_t rb, pb, tb;
+    sizes(std::min(65535, nseg), &rb, &pb, &tb);
+    void* scratch = nullptr;
+    BDE_TRY(voxel_scratch_acquire(rb + pb + tb + 512, stream, &scratch));
+    if (!scratch)                                       // too large or no memory: the streaming kernel needs no scratch
+        return voxel_tile_launch<NATIVE>(xs, ys, ts, ps, starts, ends, n_single, nseg, nb, H, W, grids, oob, stream, n_cols);
     for (int w0 = 0; w0 < nseg; w0 += 65535) {
         const int nw = std::min(65535, nseg - w0);
-        const size_t nrec = (size_t)nw * nchunks * VB_CHUNK;
-        const size_t rec_bytes = nrec * sizeof(VoxelRec), p_bytes = NATIVE ? 0 : nrec * sizeof(float);
-        const size_t tab_bytes = (size_t)nw * nchunks * (ntiles + 1) * sizeof(int);
-        void* scratch = nullptr;
-        BDE_TRY(voxel_scratch(rec_bytes + p_bytes + tab_bytes + 512, &scratch));
+        size_t rec_bytes, p_bytes, tab_bytes;
+        sizes(nw, &rec_bytes, &p_bytes, &tab_bytes);
         VoxelRec* recs = (VoxelRec*)scratch;
         float* pvals = NATIVE ? nullptr : (float*)((char*)scratch + rec_bytes);
         int* table = (int*)((char*)scratch + ((rec_bytes + p_bytes + 255) / 256) * 256);
@@ -667,7 +703,9 @@ static inline int voxel_bucket_launch(const void* xs, const void* ys, const void
         hipLaunchKernelGGL(voxel_tile_from_buckets_kernel<NATIVE>, dim3((unsigned)ntiles, (unsigned)nw), dim3(1024), lds, stream, recs, pvals, table,
                            nb, H, W, TH, TW, ntw, ntiles, nchunks, grids + (long)w0 * nb * H * W);
     }
-    BDE_HIP(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(scratch, stream);
+    BDE_HIP(le);
     return BDE_OK;
 }
 

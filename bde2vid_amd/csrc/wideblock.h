@@ -26,7 +26,7 @@
 #include "common.h"
 #include "conv_mfma.h"
 #include "token_fused.h"
-#include "winblock_sb.h"        // ws_split_pair
+#include "winblock_sb.h"        // ws_split_pair_g
 
 namespace bde {
 
@@ -92,6 +92,7 @@ struct TokGemmArgs {
     // W[16 rt + m][32 ks + (jj < 4 ? 4 jj + g4 : 16 + 4 (jj - 4) + g4)] * 2^e;  *w_unscale = 2^-e
     const unsigned short* wS;
     const float* w_unscale;
+    unsigned* ovf;         // ... and the forward's overflow word: range guard of the two-term format (split.h)
 };
 
 // A wave computes MT row tiles x NT token tiles over 1/KSPLIT of K.  KSPLIT == 1: the four waves of a workgroup take
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, gm = 0.f;
     for (int k0 = 0; k0 < nks; k0 += KS) {
         wf4 xv[KS][2];                                      // the token operand of the whole group goes out first
 #pragma unroll
@@ -396,10 +397,10 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
                 s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
                       ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
                 unsigned t[4][2];
-                ws_split_pair<2>(x0[0], x0[1], t[0]);
-                ws_split_pair<2>(x0[2], x0[3], t[1]);
-                ws_split_pair<2>(x1[0], x1[1], t[2]);
-                ws_split_pair<2>(x1[2], x1[3], t[3]);
+                ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
+                ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
+                ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
+                ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
                 sb8 bfr[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
         }
     }
     if (MT >= 8) load_rows();
+    sb_guard_flush(gm, a.ovf);
     // LayerNorm statistics of each lane's token: the four g4 lanes of a column hold the four channel residues
     float mu = 0.f, rstd = 1.f;
     if (a.lnsum) {
@@ -471,10 +473,11 @@ struct ProjFc1Args {
     long x_bs, hid_bs;
     int C, hidden, HW, ntile;
     int mask_w, mask_pt, mask_pl; // dilated-window coverage mask on the proj output (uncovered pixels: shortcut only)
+    unsigned* ovf;                // range guard of the two-term format (split.h)
 };
 // acc[m] += W[row tiles rt0 .. rt0 + 3] x over K = 32 nks; xp = the lane's wf4 of channel group 0 (consecutive groups 64 wf4 apart)
 template <typename XP>
-__device__ __forceinline__ void frag_gemm4(XP xp, const sb8* wbase, int rt0, int nks, f32x4 (&acc)[4]) {
+__device__ __forceinline__ void frag_gemm4(XP xp, const sb8* wbase, int rt0, int nks, f32x4 (&acc)[4], float& gm) {
     constexpr int KS = 8;
     const sb8* wp[4];
 #pragma unroll
@@ -504,10 +507,10 @@ __device__ __forceinline__ void frag_gemm4(XP xp, const sb8* wbase, int rt0, int
             if (k0 + k < nks) {
                 const wf4 x0 = xv[k][0], x1 = xv[k][1];
                 unsigned t[4][2];
-                ws_split_pair<2>(x0[0], x0[1], t[0]);
-                ws_split_pair<2>(x0[2], x0[3], t[1]);
-                ws_split_pair<2>(x1[0], x1[1], t[2]);
-                ws_split_pair<2>(x1[2], x1[3], t[3]);
+                ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
+                ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
+                ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
+                ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
                 sb8 bfr[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
@@ -542,7 +545,9 @@ __global__ __launch_bounds__(256) void projfc1_sb_kernel(const ProjFc1Args a) {
                 bp[m][r] = a.bproj[rt * 16 + g4 * 4 + r];
             }
         }
-        frag_gemm4(ap, reinterpret_cast<const sb8*>(a.wprojS) + lane, 4 * wave, nks, acc);
+        float gm = 0.f;
+        frag_gemm4(ap, reinterpret_cast<const sb8*>(a.wprojS) + lane, 4 * wave, nks, acc, gm);
+        sb_guard_flush(gm, a.ovf);
         bool covered = true;
         if (a.mask_w > 0 && tok < a.HW) {
             const int y = tok / a.mask_w, x = tok - y * a.mask_w;
@@ -587,7 +592,9 @@ __global__ __launch_bounds__(256) void projfc1_sb_kernel(const ProjFc1Args a) {
         f32x4 acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        frag_gemm4(reinterpret_cast<const wf4*>(X1) + lane, reinterpret_cast<const sb8*>(a.wfc1S) + lane, rt0, nks, acc);
+        float gm = 0.f;
+        frag_gemm4(reinterpret_cast<const wf4*>(X1) + lane, reinterpret_cast<const sb8*>(a.wfc1S) + lane, rt0, nks, acc, gm);
+        sb_guard_flush(gm, a.ovf);
         const float us = a.fc1_unscale[0];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -643,6 +650,7 @@ struct AttnTokArgs {
     // SPLIT: the same rows as two fp16 terms in the k order of FRAG16 group pairs (TokGemmArgs::wS), *wqkv_unscale their inverse scale
     const unsigned short* wqkvS;
     const float* wqkv_unscale;
+    unsigned* ovf;                // range guard of the two-term format (split.h)
 };
 
 // softmax(q k^T + bias) v for one (window, head), head_dim 16; four waves = four tiles of 16 queries (attn_mfma.h).
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
             const sb8* wkS = reinterpret_cast<const sb8*>(a.wqkvS) + ((long)(ngk + head) * nks * 2) * 64 + lane;
             const sb8* wvS = reinterpret_cast<const sb8*>(a.wqkvS) + ((long)(2 * ngk + head) * nks * 2) * 64 + lane;
             constexpr int U = 2;                                   // k-steps of 32 (two channel groups each) per register buffer
+            float gm = 0.f;
             wf4 xb[2][2 * U];
             sb8 fq[2][U][2], fk[2][U][2], fv[2][U][2];
             auto fetch = [&](int buf, int ks0) {
@@ -718,10 +727,10 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
                     s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
                           ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
                     unsigned t[4][2];
-                    ws_split_pair<2>(x0[0], x0[1], t[0]);
-                    ws_split_pair<2>(x0[2], x0[3], t[1]);
-                    ws_split_pair<2>(x1[0], x1[1], t[2]);
-                    ws_split_pair<2>(x1[2], x1[3], t[3]);
+                    ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
+                    ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
+                    ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
+                    ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
                     sb8 bfr[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
@@ -737,6 +746,7 @@ __global__ __launch_bounds__(256) void attn_tok16_kernel(const AttnTokArgs a) {
                 if (ks + 2 * U < nks) fetch(0, ks + 2 * U);
                 if (ks + U < nks) compute(1, ks + U);
             }
+            sb_guard_flush(gm, a.ovf);
             const float us = a.wqkv_unscale[0];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { aq[r] *= us; ak[r] *= us; av[r] *= us; }

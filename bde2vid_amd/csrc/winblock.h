@@ -71,6 +71,7 @@ struct WinArgs {
     int nA, nB, nrowsA, ncolsB, rowsA[3], colsB[3];
     int ke;                         // such pixels carried per window (0: extra workgroups take them)
     unsigned long long* stamps;     // diagnostics only: s_memtime per phase, [block < 64][wave < 4][8]
+    unsigned* ovf;                  // winblock_sb.h, two-term operands: the forward's overflow word (range guard, split.h)
 };
 
 #define WB_STAMP(i)                                                                               \

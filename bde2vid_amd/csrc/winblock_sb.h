@@ -66,7 +66,8 @@ __device__ __forceinline__ float ws_h_hi(unsigned d) {
     return f;
 }
 // (x0, x1) = the sum of TERMS terms, each term a packed 16-bit pair; the remainders are exact in fp32.  (No special case for
-// Inf or, with fp16 terms, |x| >= 65520: the later terms become NaN and so does the block's output -- loud, not wrong.)
+// Inf or, with fp16 terms, |x| >= 65520: the later terms become NaN; ws_split_pair_g reports such a value through the range guard
+// of split.h, and the forward is recomputed with three bf16 terms.)
 template <int TERMS>
 __device__ __forceinline__ void ws_split_pair(float x0, float x1, unsigned (&t)[TERMS]) {
     if constexpr (TERMS == 2) {
@@ -79,6 +80,14 @@ __device__ __forceinline__ void ws_split_pair(float x0, float x1, unsigned (&t)[
         const float q0 = r0 - __builtin_bit_cast(float, t[1] << 16), q1 = r1 - __builtin_bit_cast(float, t[1] & 0xffff0000u);
         t[2] = ws_pk(q0, q1);
     }
+}
+
+// ... with the range guard of the two-term format: gm = max(gm, |x0|, |x1|) (one v_max3_f32), flushed by the caller per phase so
+// that no guard register lives across the attention phase (128-register cap)
+template <int TERMS>
+__device__ __forceinline__ void ws_split_pair_g(float x0, float x1, unsigned (&t)[TERMS], float& gm) {
+    if constexpr (TERMS == 2) gm = sb_guard_max2(gm, x0, x1);
+    ws_split_pair<TERMS>(x0, x1, t);
 }
 
 // Experiment switch (tools/build_variant.sh ... -DWS_ATTN_KEY_OUTER=1): key tile outermost in the attention phase, a key tile's V
@@ -244,10 +253,12 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
     // this thread's token as split terms into operand tile `jl` of XS (chunks g4 and 4 + g4)
     auto write_split = [&](int jl) {
         unsigned t[2][4][TERMS];
+        float gm = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) ws_split_pair<TERMS>(xv[8 * h + 2 * p], xv[8 * h + 2 * p + 1], t[h][p]);
+            for (int p = 0; p < 4; ++p) ws_split_pair_g<TERMS>(xv[8 * h + 2 * p], xv[8 * h + 2 * p + 1], t[h][p], gm);
+        if (TERMS == 2) sb_guard_flush(gm, a.ovf);
 #pragma unroll
         for (int k = 0; k < TERMS; ++k)
 #pragma unroll
@@ -513,22 +524,24 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             if (lane < 16) {
                 // the head's four output channels of a token = half of operand chunk h >> 1: 8 bytes per term, already split
                 unsigned char* ao = XS + (h >> 1) * 256 + lane * 16 + (h & 1) * 8;
+                float gm = 0.f;
 #pragma unroll
                 for (int i = 0; i < NQT; ++i) {
                     const float inv = 1.f / pl[i];
                     unsigned t[2][TERMS];
-                    ws_split_pair<TERMS>(po[i][0] * inv, po[i][1] * inv, t[0]);
-                    ws_split_pair<TERMS>(po[i][2] * inv, po[i][3] * inv, t[1]);
+                    ws_split_pair_g<TERMS>(po[i][0] * inv, po[i][1] * inv, t[0], gm);
+                    ws_split_pair_g<TERMS>(po[i][2] * inv, po[i][3] * inv, t[1], gm);
 #pragma unroll
                     for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + i * WS_XS_TILE) = uint2{t[0][k], t[1][k]};
                 }
                 // token tile 3: column 0 = query 48, the other columns carry no attention output
                 const float inv48 = 1.f / l48;
                 unsigned t[2][TERMS];
-                ws_split_pair<TERMS>(lane == 0 ? o48[0] * inv48 : 0.f, lane == 0 ? o48[1] * inv48 : 0.f, t[0]);
-                ws_split_pair<TERMS>(lane == 0 ? o48[2] * inv48 : 0.f, lane == 0 ? o48[3] * inv48 : 0.f, t[1]);
+                ws_split_pair_g<TERMS>(lane == 0 ? o48[0] * inv48 : 0.f, lane == 0 ? o48[1] * inv48 : 0.f, t[0], gm);
+                ws_split_pair_g<TERMS>(lane == 0 ? o48[2] * inv48 : 0.f, lane == 0 ? o48[3] * inv48 : 0.f, t[1], gm);
 #pragma unroll
                 for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + 3 * WS_XS_TILE) = uint2{t[0][k], t[1][k]};
+                if (TERMS == 2) sb_guard_flush(gm, a.ovf);
             }
             // proj fragments: requested only now -- the phase above sits at the 128-register cap, and a spilled register there costs
             // more than this load's latency (part of it passes in the barrier)
@@ -591,8 +604,10 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             }
             wb_sync();                              // every wave has read its attention-output fragments: x1 takes their place
             unsigned t[2][TERMS];
-            ws_split_pair<TERMS>(x1v[0], x1v[1], t[0]);
-            ws_split_pair<TERMS>(x1v[2], x1v[3], t[1]);
+            float gm = 0.f;
+            ws_split_pair_g<TERMS>(x1v[0], x1v[1], t[0], gm);
+            ws_split_pair_g<TERMS>(x1v[2], x1v[3], t[1], gm);
+            if (TERMS == 2) sb_guard_flush(gm, a.ovf);
             unsigned char* d = XS + i * WS_XS_TILE + (rt * 2 + (g4 >> 1)) * 256 + col * 16 + (g4 & 1) * 8;
 #pragma unroll
             for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(d + k * WS_XS_TERM) = uint2{t[0][k], t[1][k]};
@@ -623,6 +638,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             ss[r] = psfc1[row0 + r];
             bb[r] = pbfc1[row0 + r];
         }
+        float gm = 0.f;
 #pragma unroll 2
         for (int i = 0; i < 4; ++i) {
             sb8 b0[TERMS], b1[TERMS];
@@ -644,12 +660,13 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = gelu_f(rs * (WS_US(acc[r], 2) - mu * ss[r]) + bb[r]);
             unsigned t[2][TERMS];
-            ws_split_pair<TERMS>(hv[0], hv[1], t[0]);
-            ws_split_pair<TERMS>(hv[2], hv[3], t[1]);
+            ws_split_pair_g<TERMS>(hv[0], hv[1], t[0], gm);
+            ws_split_pair_g<TERMS>(hv[2], hv[3], t[1], gm);
             unsigned char* d = HS + i * WS_HID_TILE + (wave * 2 + (g42 >> 1)) * 256 + col2 * 16 + (g42 & 1) * 8;
 #pragma unroll
             for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(d + k * WS_HID_TERM) = uint2{t[0][k], t[1][k]};
         }
+        if (TERMS == 2) sb_guard_flush(gm, a.ovf);
     }
     wb_sync();
     { const int lane = lane2; WB_STAMP(5); }

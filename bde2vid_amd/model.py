@@ -41,6 +41,7 @@ class BDE2VID:
         self._h = None
         self._loaded = False
         self._ext_streams = {}              # pipelined mode: torch views of the library's internal streams
+        self._inflight = []                 # pipelined mode: inputs / outputs of calls not yet waited for (see forward)
 
     # ---- reference surface ---------------------------------------------------------------
     @property
@@ -165,12 +166,20 @@ class BDE2VID:
             for t in evs:
                 t.record_stream(es)
             out.record_stream(es)
+            # ... and keep the output buffer alive until wait(): a forward whose operands leave the range of the two-term
+            # format is recomputed there ("sb_auto", csrc/split.h) into the same buffer, long after the first run is done with it
+            self._inflight.append(out)
+            if len(self._inflight) > 8:
+                del self._inflight[0]
         return [out[t] for t in range(T)]
 
     def wait(self):
         """Pipelined mode only (set_tuning('pipeline', 2)): order the outputs of all forward calls issued so
         far into the current stream.  Call before reading them (a device synchronize also suffices)."""
-        _lib.check(_lib.lib().bde_wait_outputs(self._h, C.c_void_p(_stream_ptr(self.device))))
+        try:
+            _lib.check(_lib.lib().bde_wait_outputs(self._h, C.c_void_p(_stream_ptr(self.device))))
+        finally:
+            self._inflight.clear()
         return self
 
     def get_info(self, key: str) -> int:

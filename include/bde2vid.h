@@ -67,6 +67,11 @@ typedef struct bde_config {
 #define BDE_ERR_STATE (-2)
 #define BDE_ERR_HIP (-3)
 #define BDE_ERR_UNSUPPORTED (-4)
+#define BDE_ERR_RANGE (-5)       /* an activation left the range of the two-term operand format and "sb_auto" is 0 */
+
+/* Version of this header; bde_abi_version() returns the one the library was built from (bde2vid_amd/_lib.py refuses a mismatch).
+ * 4: BDE_ERR_RANGE, "sb_auto" and the range guard of the two-term operand format. */
+#define BDE_ABI_VERSION 4
 
 const char* bde_last_error(void);
 int bde_abi_version(void);
@@ -91,8 +96,13 @@ int bde_alloc_packed(bde_model* m);
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* events[t]: device fp32 [B][num_bins][Hp][Wp] (NCHW);  images[t]: device fp32 [B][1][Hp][Wp].
  * Hp, Wp multiples of 2^num_encoders, feature maps at attention levels >= 7x7.
- * Recurrent state always starts from zero (bde2vid.py:31).  Launches on `stream`, returns
- * without synchronising. */
+ * Recurrent state always starts from zero (bde2vid.py:31).  Launches on `stream`.
+ * Range guard of the default operand format (two fp16 terms, csrc/split.h): a forward in which an activation reaches 65520 is
+ * detected on the device.  With "sb_auto" = 1 (default) the model then switches to three bf16 terms (fp32's exponent range) for good
+ * and the forward is recomputed into the same `images`; with "sb_auto" = 0 the call fails with BDE_ERR_RANGE.  In the default
+ * mode ("pipeline" = 1) this happens inside bde_forward, which therefore waits for the forward up to its last convolution
+ * before it returns (the convolution itself is still in flight; with "sb_terms" = 3 nothing is checked and nothing waited for);
+ * in pipelined mode it happens in bde_wait_outputs, or in the bde_forward call that reuses the workspace slot. */
 int bde_forward(bde_model* m, const float* const* events, int32_t T, int32_t B, int32_t Hp, int32_t Wp,
                 float* const* images, void* stream);
 /* Copy a named intermediate of the last bde_forward into `dst` (device): "head", "merged<l>"
@@ -115,7 +125,9 @@ int bde_split_buffer(bde_model* m, const char* what, int32_t level, int32_t dire
 /* Pipelined mode ("pipeline" = 2..4, see bde_set_tuning): consecutive bde_forward calls (independent
  * sequences) rotate over that many internal streams and workspaces; inputs are ordered after the
  * caller's `stream`, but the outputs of a call are only ordered into `stream` by bde_wait_outputs
- * (call it before anything on `stream` reads them).  Default is "pipeline" = 1: no such call needed. */
+ * (call it before anything on `stream` reads them; `images` of the calls issued since the last bde_wait_outputs must stay
+ * valid until it returns: it is also where a forward that left the range of the two-term operand format is recomputed, see
+ * bde_forward, and where BDE_ERR_RANGE is reported).  Default is "pipeline" = 1: no such call needed. */
 int bde_wait_outputs(bde_model* m, void* stream);
 
 /* Scheduling knobs (results are unchanged up to fp32 summation order).  Keys:
@@ -125,8 +137,10 @@ int bde_wait_outputs(bde_model* m, void* stream);
  *   "fused_min_tiles": a level with at least this many 32-pixel tiles runs the post-softmax part of an
  *                      attention block as one fused kernel instead of three GEMM launches (default 160).
  *   "sb_terms": operand format of every split kernel (csrc/split.h): 2 (default) = two fp16 terms, three MFMAs per fp32
- *              block, fp32-equivalent accuracy, finite activations must stay below 65520 (beyond it they turn infinite and the
- *              frames non-finite, never wrong); 3 = three bf16 terms, six MFMAs, fp32's exponent range.
+ *              block, fp32-equivalent accuracy, finite activations must stay below 65520 -- guarded, see "sb_auto"; 3 = three bf16
+ *              terms, six MFMAs, fp32's exponent range.
+ *   "sb_auto": 1 (default) = a forward in which an activation reaches 65520 under "sb_terms" = 2 is recomputed with three bf16
+ *              terms and the model keeps that format (bde_get_info "sb_latched"); 0 = such a forward fails with BDE_ERR_RANGE.
  *   "conv_sb": 1 (default) runs the batched convolutions that have a split-operand shape (csrc/conv_sb.h) on the 16-bit
  *              matrix cores (fp32-equivalent); 0 keeps every convolution -- and the recurrent step -- on the fp32 kernels.
  *   "xcd_remap": 1 (default) orders the workgroups of the batched convolutions so that each XCD's L2 sees one contiguous
@@ -150,7 +164,9 @@ int bde_wait_outputs(bde_model* m, void* stream);
 int bde_set_tuning(bde_model* m, const char* key, int64_t value);
 /* Read back the state the measurement has to be honest about: "debug_skip" (non-zero = stages skipped, results
  * invalid), "graph" (0 also after a failed capture), "graphs_live" (workspaces replaying a captured launch
- * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "sb_terms", "lstm_sb", "lstm_sbk", "lstm_fuse_x", "wide_kv_sb", "wide_fuse_mlp", "last_stream",
+ * sequence), "pipeline", "winblock", "winblock_sb", "wide", "conv_sb", "sb_terms", "sb_auto", "sb_latched" (1 after the range guard
+ * switched the model to three bf16 terms), "sb_overflows" (forwards that left the range so far), "sb_overflow_word" (the raw
+ * overflow word of slot 0, cleared by the read: set by bde_op_* / bde_split_* calls, which do not recompute), "lstm_sb", "lstm_sbk", "lstm_fuse_x", "wide_kv_sb", "wide_fuse_mlp", "last_stream",
  * "device", "packed_numel"; and which convolutions the latest forward ran on split operands (csrc/conv_sb.h): "sb_head",
  * "sb_enc<l>", "sb_gx<l>" (0 when the step contracts [x | h] itself: no such launch), "sb_dec<j>" (0 / 1), and
  * "sb_lstm<l>": the recurrent steps of level l ran on the fused split-operand step kernel (csrc/lstm_sb.h).

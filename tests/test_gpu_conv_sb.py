@@ -225,7 +225,8 @@ def test_non_finite_activations_same_class_on_both_arithmetic_paths(model_a):
 
 def test_range_of_the_two_term_format(model_a):
     """fp16 terms keep 5 exponent bits (csrc/split.h): an activation of 65520 or more turns infinite in the default two-term
-    format -- the output is non-finite on that activation's footprint, never a wrong finite number -- while three bf16 terms
+    format -- the output is non-finite on that activation's footprint and the range guard raises the overflow word (a whole
+    forward is then recomputed with three terms: tests/test_gpu_e2e.py::test_range_guard_*) -- while three bf16 terms
     (set_tuning('sb_terms', 3)) and the fp32 kernels carry it; just below the limit all three agree with torch.  Tiny
     activations (fp16 subnormal range) keep an absolute accuracy of 2^-25."""
     from bde2vid_amd import ops
@@ -252,7 +253,11 @@ def test_range_of_the_two_term_format(model_a):
     big[0, 4, 33, 10, 12] = 1.0e5                       # beyond fp16
     big[1, 7, 60, 3, 3] = 65000.0                       # within
     ref = ref_of(big)
-    y2, y3 = run(big, 2), run(big, 3)
+    m.get_info('sb_overflow_word')                      # (reading clears it)
+    y3 = run(big, 3)
+    assert m.get_info('sb_overflow_word') == 0          # three bf16 terms: nothing to guard
+    y2 = run(big, 2)
+    assert m.get_info('sb_overflow_word') == 1          # the range guard saw the 1e5 (an op-level call does not recompute)
     scale = float(ref.abs().max())
     assert torch.isfinite(y3).all() and maxabs(y3.double(), ref) <= 2e-6 * scale
     bad = ~torch.isfinite(y2)
@@ -261,6 +266,7 @@ def test_range_of_the_two_term_format(model_a):
     tiny = base * 1e-6                                   # every low term (and many leading ones) subnormal in fp16
     ref = ref_of(tiny)
     y2 = run(tiny, 2)
+    assert m.get_info('sb_overflow_word') == 0
     assert maxabs(y2.double(), ref) <= 1e-5 * float((ref - ref.mean()).abs().max()) + 2e-7
 
 

@@ -545,3 +545,91 @@ def test_round3_kernels_agree_with_the_kernels_they_replace():
             assert torch.equal(y, y2), key
         last = torch.stack(m(inp))
         assert torch.equal(last, base), maxabs(last, base)
+
+
+def _scaled_head_model(scale):
+    """Canonical config, formula weights, the head convolution scaled so that level-0 activations pass 65520."""
+    from bde2vid_amd import canonical
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.weights import formula_state_dict
+    cfg = canonical()
+    sd = {k: v.clone() for k, v in formula_state_dict(cfg).items()}
+    for k in ('generator.head.conv2d.weight', 'generator.head.conv2d.bias'):
+        sd[k] = sd[k] * scale
+    return cfg, sd, build_model(cfg, sd, 'cuda:0')
+
+
+def test_range_guard_recomputes_with_three_terms():
+    """The default operand format (two fp16 terms, csrc/split.h) carries finite activations below 65520 only; the reference
+    computes in fp32 (submodules.py:105-114, 316-332).  With head weights scaled so that level-0 feature maps pass that limit the
+    forward is detected on the device and recomputed with three bf16 terms: the caller gets the frames of the sb_terms = 3 build,
+    not NaNs, the model keeps that format, and an ordinary model is left alone."""
+    from tests.util import golden_inputs
+    if int(__import__('os').environ.get('BDE_SB_TERMS', 2)) != 2:
+        pytest.skip('the guard belongs to the two-term format')
+    xs = golden_inputs(2, 1, 5, 184, 240, 4321)
+    inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    cfg, sd, m = _scaled_head_model(3.0e5)
+    with torch.no_grad():
+        assert m.get_info('sb_terms') == 2 and m.get_info('sb_auto') == 1
+        y = torch.stack(m(inp)).clone()
+        assert m.get_info('sb_overflows') == 1 and m.get_info('sb_latched') == 1 and m.get_info('sb_terms') == 3
+        head = m.get_intermediate('head', (2, 1, cfg.basechannels, 184, 240))
+        assert float(head.max()) > 65520.0                              # the premise: a level-0 activation beyond fp16
+        y_again = torch.stack(m(inp))                                   # the latched format: no further recomputation
+        assert m.get_info('sb_overflows') == 1
+    _, _, m3 = _scaled_head_model(3.0e5)
+    m3.set_tuning('sb_terms', 3)
+    with torch.no_grad():
+        ref = torch.stack(m3(inp))
+    assert torch.isfinite(y).all() and torch.isfinite(ref).all()
+    assert maxabs(y, ref) <= 2e-5 and maxabs(y_again, ref) <= 2e-5
+    assert float(ref.std()) > 1e-3                                       # not a saturated constant image
+    # an ordinary model never trips the guard
+    _, _, m1 = _scaled_head_model(1.0)
+    with torch.no_grad():
+        m1(inp)
+        m1(inp)
+    assert m1.get_info('sb_overflows') == 0 and m1.get_info('sb_terms') == 2 and m1.get_info('sb_latched') == 0
+
+
+def test_range_guard_error_path_and_serving_mode():
+    """"sb_auto" = 0: the same forward fails with BDE_ERR_RANGE instead (bde_forward in the default mode, bde_wait_outputs in
+    serving mode) and the model stays in the two-term format.  Serving mode with "sb_auto" = 1: three sequences in flight, one
+    of them with event counts large enough to overflow -- after wait() every sequence holds the frames of the three-term build."""
+    from bde2vid_amd import _lib
+    from tests.util import golden_inputs
+    if int(__import__('os').environ.get('BDE_SB_TERMS', 2)) != 2:
+        pytest.skip('the guard belongs to the two-term format')
+    xs = golden_inputs(2, 1, 5, 184, 240, 4321)
+    inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+    cfg, sd, m = _scaled_head_model(3.0e5)
+    m.set_tuning('sb_auto', 0)
+    with torch.no_grad():
+        with pytest.raises(_lib.RangeError):
+            m(inp)
+        assert m.get_info('sb_terms') == 2 and m.get_info('sb_overflows') == 1
+        m.set_tuning('pipeline', 2)
+        m(inp)
+        with pytest.raises(_lib.RangeError):
+            m.wait()
+        m.set_tuning('pipeline', 1)
+    # serving mode, automatic: an ordinary model, one sequence of huge voxel counts among ordinary ones
+    _, _, m2 = _scaled_head_model(1.0)
+    big = [{'events': d['events'] * 2.0e6} for d in inp]
+    seqs = [inp, inp, big, inp, big, inp, inp]
+    _, _, m3 = _scaled_head_model(1.0)
+    m3.set_tuning('sb_terms', 3)
+    with torch.no_grad():
+        ref = [torch.stack(m3(s)).clone() for s in seqs]
+        m2.set_tuning('pipeline', 3)
+        outs = [m2(s) for s in seqs]
+        m2.wait()
+        torch.cuda.synchronize()
+        m2.set_tuning('pipeline', 1)
+    assert m2.get_info('sb_latched') == 1 and m2.get_info('sb_overflows') >= 1
+    for i, (r, o) in enumerate(zip(ref, outs)):
+        o = torch.stack(o)
+        assert torch.isfinite(o).all(), i
+        # (sequences that ran before the switch keep their two-term frames: both formats are fp32-equivalent)
+        assert maxabs(o, r) <= 2e-5, i

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bde_abi_version() == 3
+    assert L.bde_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_create_rejects_bad_config_and_reports_error():
