@@ -27,6 +27,7 @@
 #include "winblock.h"
 #include "winblock_sb.h"
 #include "wideblock.h"
+#include "wide_mlp.h"
 #include "attn_mfma.h"
 #include "conv_vec.h"
 #include "conv_sb.h"
@@ -666,6 +667,7 @@ struct AttnBlock {
     long unscaleH = -1;                                       // (four floats in the packed image)
     long qkvHF = -1, qkvHF_unscale = -1;                      // q|k|v as two fp16 terms in FRAG16 k order (attn_tok16_kernel<true, true>)
     long projHF = -1, fc1HF = -1, mlpHF_unscale = -1;         // proj, fc1 likewise (projfc1_sb_kernel); unscale: {proj, fc1}
+    long fc1N = -1, fc2N = -1, mlpN_unscale = -1;             // fc1, fc2 as two fp16 terms in natural k order (mlp_fused_kernel); unscale: {fc1, fc2}
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -686,6 +688,7 @@ struct Workspace {
     float* out = nullptr;
     std::vector<float*> xenc, gx, hseq, cst, merged, mergedT, kvun, kvref, dec, qkv0;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
+    int* tile_count = nullptr;    // wide_mlp.h: per (batch, token tile) arrival counters of the fused MLP launch, zero between launches
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     float* sb = nullptr;          // split-bf16 image of the input of the convolution in flight (conv_sb.h)
     float* sb2 = nullptr;         // split-bf16 encoder output of a level, written by the encoder conv's epilogue for its gate conv
@@ -706,6 +709,7 @@ struct Workspace {
         allocs.clear();
         // no pointer outlives its allocation: the op-level entry points test them (ws.sb, ws.hsk[l], ...) before use
         ev = head = out = qkv = ao = x1 = hid = xa = xb = up = sb = sb2 = cat = fuse = rbA = rbX[0] = rbX[1] = zero_l = nullptr;
+        tile_count = nullptr;
         sb_bytes = sb2_bytes = 0;
         for (auto* v : {&xenc, &gx, &hseq, &cst, &merged, &mergedT, &kvun, &kvref, &dec, &qkv0, &gur, &ghr, &gou, &gub, &hsk, &hsb, &ghb}) v->clear();
         T = B = H = W = 0;
@@ -782,6 +786,7 @@ struct bde_model {
     hipEvent_t dir_fork[4] = {}, dir_join[4] = {};
     int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
     int wide_fuse_mlp = 1;        // ... and x1 = x + proj(.) together with GELU(fc1(LN(x1))) in one launch (projfc1_sb_kernel)
+    int wide_fuse_fc2 = 1;        // ... and fc2 + both residuals in the same launch (mlp_fused_kernel, wide_mlp.h): two launches per block
     int wide_kv_sb = 1;           // K|V GEMMs of the head_dim-16 chain on two-term split operands (tokgemm_sb_kernel, wideblock.h)
     int lstm_fuse_x = 1;          // ... and the x-part of the gates in the same contraction (no batched gate convolution, no gx round trip)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
@@ -1171,6 +1176,9 @@ static int build_packed(bde_model* m) {
                 ab.mlpHF_unscale = ar.alloc(4);
                 ab.projHF = pack16_split_frag(ar, proj.w.data(), C, C, ab.mlpHF_unscale);
                 ab.fc1HF = pack16_split_frag(ar, fc1.w.data(), hid, C, ab.mlpHF_unscale + 1);
+                ab.mlpN_unscale = ar.alloc(4);
+                ab.fc1N = pack16_split(ar, fc1.w.data(), hid, C, 2, ab.mlpN_unscale);
+                ab.fc2N = pack16_split(ar, fc2.w.data(), C, hid, 2, ab.mlpN_unscale + 1);
             }
             if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
                 ab.projS = pack16_split(ar, proj.w.data(), C, C, 3, -1);
@@ -1497,6 +1505,10 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.hid, 4 * max_attn));
         BDE_TRY(ws_alloc(ws, &ws.xa, max_attn));
         BDE_TRY(ws_alloc(ws, &ws.xb, max_attn));
+        float* cnt = nullptr;                              // one counter per 16 tokens of the largest attention frame
+        BDE_TRY(ws_alloc(ws, &cnt, max_attn / 16 + 64));
+        BDE_HIP(hipMemset(cnt, 0, sizeof(int) * (size_t)(max_attn / 16 + 64)));
+        ws.tile_count = reinterpret_cast<int*>(cnt);
     }
     ws.T = T; ws.B = B; ws.H = H; ws.W = W;
     return BDE_OK;
@@ -2154,6 +2166,37 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
         float* dst = (last && out) ? out : (x == ws.xa ? ws.xb : ws.xa);     // out == nullptr: the caller only wants out_nchw
         // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only; DTransformer.py:299, 79-82)
         // hidden = GELU(fc1(LN(x1))): with two-term operands both in one launch (projfc1_sb_kernel)
+        if (m->wide_fuse_mlp && m->wide_fuse_fc2 && m->sb_terms == 2 && ab.projHF >= 0 && ab.fc1N >= 0 && C == 256 && ab.fc1.Cout == 4 * C &&
+            ws.tile_count) {
+            // the whole token half of the block in one launch (wide_mlp.h)
+            MlpFusedArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.ao = ws.ao; fa.x = x;
+            fa.wprojS = reinterpret_cast<const unsigned short*>(m->P(ab.projHF));
+            fa.wfc1S = reinterpret_cast<const unsigned short*>(m->P(ab.fc1N));
+            fa.wfc2S = reinterpret_cast<const unsigned short*>(m->P(ab.fc2N));
+            fa.unscale_proj = m->P(ab.mlpHF_unscale);
+            fa.unscale_mlp = m->P(ab.mlpN_unscale);
+            fa.bproj = m->P(ab.proj.b_off);
+            fa.bfc1 = m->P(ab.fc1.b_off);
+            fa.sfc1 = m->P(ab.fc1.s_off);
+            fa.bfc2 = m->P(ab.fc2.b_off);
+            fa.part = ws.hid;                                // (the hidden activations never leave the workgroups)
+            fa.count = ws.tile_count;
+            fa.out = dst;
+            fa.out_nchw = last ? out_nchw : nullptr;
+            fa.addres = last ? addres : nullptr;
+            fa.x_bs = (long)ntile * 16 * C;
+            fa.nchw_bs = HW * C;
+            fa.HW = (int)HW; fa.ntile = ntile; fa.B = B;
+            fa.mask_w = dil ? W : 0; fa.mask_pt = pt; fa.mask_pl = plft;
+            fa.ovf = m->ovf();
+            fa.stamps = m->tok_debug == 21 ? m->tok_stamps : nullptr;
+            ProfScope ps(m, pname("wide_mlp", l), s);
+            BDE_TRY(mlp_fused_launch(fa, s));
+            x = dst;
+            continue;
+        }
         if (m->wide_fuse_mlp && m->sb_terms == 2 && ab.projHF >= 0 && C == 256 && ab.fc1.Cout == 4 * C) {
             ProjFc1Args pa;
             memset(&pa, 0, sizeof pa);
@@ -3003,6 +3046,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "wide_fuse_qkv") { m->wide_fuse_qkv = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_kv_sb") { m->wide_kv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_fuse_mlp") { m->wide_fuse_mlp = (int)value; return BDE_OK; }
+    if (std::string(key) == "wide_fuse_fc2") { m->wide_fuse_fc2 = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") {
         if (m->conv_sb != (int)value)
             for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it
@@ -3074,6 +3118,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "lstm_fuse_x") *value = m->lstm_fuse_x;
     else if (k == "wide_kv_sb") *value = m->wide_kv_sb;
     else if (k == "wide_fuse_mlp") *value = m->wide_fuse_mlp;
+    else if (k == "wide_fuse_fc2") *value = m->wide_fuse_fc2;
     else if (k == "sb_terms") *value = m->sb_terms;
     else if (k == "sb_auto") *value = m->sb_auto;
     else if (k == "sb_overflows") *value = m->sb_overflows;       // forwards settled so far whose two-term operands left fp16's range

@@ -1,4 +1,5 @@
-"""Level-2 attention chain of config A (23x30 map, 256 ch): HIP-event time per launch of every kernel of the chain.
+"""Level-2 attention chain of config A (23x30 map, 256 ch): HIP-event time per launch of every kernel of the chain, for each
+setting of the chain's switches, and the difference of each setting's result from the all-fp32 split path.
 GPU box:  python tools/wide_bench.py [H W]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,10 +20,15 @@ m.set_tuning('wide', 0)
 y_old = ops.dframe_attention(m, 2, bufs)
 m.set_tuning('wide', 1)
 print('max |wide - split path| over 6 blocks:', float((y - y_old).abs().max()))
-for fuse in (0, 1):
-    m.set_tuning('wide_fuse_qkv', fuse)
+SETTINGS = [dict(wide_fuse_fc2=0), dict(wide_fuse_fc2=1)]
+if 'wide_core2' in os.environ.get('WIDE_KEYS', ''):
+    SETTINGS += [dict(wide_fuse_fc2=1, wide_core2=0), dict(wide_fuse_fc2=1, wide_core2=1)]
+for st in SETTINGS:
+    for k, v in st.items():
+        m.set_tuning(k, v)
     yf = ops.dframe_attention(m, 2, bufs)
-    print(f'wide_fuse_qkv={fuse}: max |y - split path| {float((yf - y_old).abs().max()):.3e}')
+    yf2 = ops.dframe_attention(m, 2, bufs)
+    print(f'{st}: max |y - split path| {float((yf - y_old).abs().max()):.3e}  repeatable {bool(torch.equal(yf, yf2))}')
     L.bde_profile_reset(m._h, 1)
     for _ in range(20):
         ops.dframe_attention(m, 2, bufs)
