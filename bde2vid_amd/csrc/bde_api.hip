@@ -28,6 +28,7 @@
 #include "winblock_sb.h"
 #include "wideblock.h"
 #include "wide_mlp.h"
+#include "wide_core.h"
 #include "attn_mfma.h"
 #include "conv_vec.h"
 #include "conv_sb.h"
@@ -671,6 +672,7 @@ struct AttnBlock {
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
+    long biasW_off = -1;    // ... and in score-tile order with the keys slot-major (wide_core.h: head_dim 16 levels)
 };
 struct AttnLevel {
     int depth = 0, C = 0;
@@ -787,6 +789,8 @@ struct bde_model {
     int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
     int wide_fuse_mlp = 1;        // ... and x1 = x + proj(.) together with GELU(fc1(LN(x1))) in one launch (projfc1_sb_kernel)
     int wide_fuse_fc2 = 1;        // ... and fc2 + both residuals in the same launch (mlp_fused_kernel, wide_mlp.h): two launches per block
+    int wide_core2 = 1;           // the window half of such a block as wide_core_kernel (wide_core.h): weights by LDS-DMA, K | V of the
+                                  // refined neighbour frame computed inside (no K|V GEMM launch between two frames)
     int wide_kv_sb = 1;           // K|V GEMMs of the head_dim-16 chain on two-term split operands (tokgemm_sb_kernel, wideblock.h)
     int lstm_fuse_x = 1;          // ... and the x-part of the gates in the same contraction (no batched gate convolution, no gx round trip)
     int lstm_sb_mode = 0;         // recurrent step as conv_sb + pointwise kernel: 0 off (default: measured slower), 1 wherever it fits, -1 by estimate
@@ -1147,6 +1151,22 @@ static int build_packed(bde_model* m) {
                                         v = bt[((long)h * N + n) * 49 + mq];
                                     }
                                     bfp[((((long)h * 4 + qi) * WB_NT + j) * 64 + ln) * 4 + r] = v;
+                                }
+            }
+            if (C % 64 == 0 && hd == 16 && N <= 160) {
+                // wide_core.h: score tile (query tile qi, key tile j) in the C/D register order of the 16x16x4 MFMA, keys in the
+                // reference's slot-major order: [head][qi][j][lane][r], key = 16 j + 4 (lane >> 4) + r, query = 16 qi + (lane & 15)
+                ab.biasW_off = ar.alloc((long)heads * 4 * 10 * 256);
+                float* bwp = ar.host.data() + ab.biasW_off;
+                bt = ar.host.data() + ab.bias_off;
+                for (int h = 0; h < heads; ++h)
+                    for (int qi = 0; qi < 4; ++qi)
+                        for (int j = 0; j < 10; ++j)
+                            for (int ln = 0; ln < 64; ++ln)
+                                for (int r = 0; r < 4; ++r) {
+                                    const int u = 16 * j + 4 * (ln >> 4) + r;
+                                    const int mq = std::min(16 * qi + (ln & 15), 48);
+                                    bwp[((((long)h * 4 + qi) * 10 + j) * 64 + ln) * 4 + r] = u < N ? bt[((long)h * N + u) * 49 + mq] : -1e30f;
                                 }
             }
             DenseLayer proj;
@@ -2107,8 +2127,16 @@ static int run_tokgemm(bde_model* m, const char* span, int l, long w_off, const 
 //   kvslot[d]: token-major K|V stack [B][HW][depth*2C] of slot d's frame (nullptr = zero frame; ignored for q_idx)
 //   addres   : FRAG16 tensor added to the result (merged[t]) or nullptr;   out: FRAG16;   out_nchw: optional [B][C][HW]
 //   qkv_first: token-major q|k|v [B][HW][3C] of block blk0 for xq if already computed (batched over T)
+//   prev_frag / prev_slot: FRAG16 frame of ONE refined neighbour (buffer slot prev_slot) whose K | V the attention core computes
+//              itself (wide_core.h) instead of reading kvslot[prev_slot]; nullptr = none
+static bool wide_core2_ok(const bde_model* m, int l) {
+    const AttnLevel& al = m->attn[l];
+    return m->wide_core2 && m->wide_fuse_qkv && m->wide_kv_sb && m->sb_terms == 2 && al.C == 256 && m->cfg.num_heads * 16 == al.C &&
+           al.depth > 0 && al.blocks[0].biasW_off >= 0 && al.blocks[0].qkvHF >= 0;
+}
 static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const float* const* kvslot, const float* addres, float* out,
-                                    float* out_nchw, int B, int H, int W, int blk0, int nblk, const float* qkv_first, hipStream_t s) {
+                                    float* out_nchw, int B, int H, int W, int blk0, int nblk, const float* qkv_first, hipStream_t s,
+                                    const float* prev_frag = nullptr, int prev_slot = -1) {
     const bde_config& c = m->cfg;
     Workspace& ws = m->W();
     const AttnLevel& al = m->attn[l];
@@ -2122,6 +2150,35 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
         const AttnBlock& ab = al.blocks[i];
         const bool dil = (i % 2) == 1;                       // DTransformer.py:362
         const bool last = (i == blk0 + nblk - 1);
+        if (wide_core2_ok(m, l)) {
+            WideCoreArgs a;
+            memset(&a, 0, sizeof a);
+            a.x = x;
+            a.xp = prev_frag;
+            a.x_bs = (long)ntile * 16 * C;
+            a.q_slot = c.q_idx;
+            a.p_slot = prev_frag ? prev_slot : -1;
+            for (int d = 0; d < D; ++d) {
+                a.kv[d] = nullptr;
+                if (d == c.q_idx || (prev_frag && d == prev_slot) || !kvslot[d]) continue;
+                a.kv[d] = kvslot[d]; a.kv_bs[d] = HW * al.depth * 2 * C; a.kv_ld[d] = al.depth * 2 * C;
+                a.k_off[d] = i * 2 * C; a.v_off[d] = i * 2 * C + C;
+            }
+            a.kvpad = m->P(ab.kvpad_off);
+            a.biasW = m->P(ab.biasW_off);
+            a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(ab.qkvHF));
+            a.wqkv_unscale = m->P(ab.qkvHF_unscale);
+            a.bqkv = m->P(ab.qkv.b_off);
+            a.sqkv = m->P(ab.qkv.s_off);
+            a.out = ws.ao;
+            a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw;
+            a.pt = pt; a.pl = plft; a.nWw = (W + pw) / 7; a.dilated = dil ? 1 : 0; a.ntile = ntile;
+            a.ovf = m->ovf();
+            a.stamps = m->tok_debug == 22 ? m->tok_stamps : nullptr;
+            ProfScope ps(m, pname("wide_core", l), s);
+            BDE_TRY(wide_core_launch(a, B, s));
+        } else {
+        BDE_REQUIRE(prev_frag == nullptr, "wide chain: K | V of the refined frame are expected from the attention core");
         const float* qkv = ws.qkv;
         const bool fuse_qkv = m->wide_fuse_qkv != 0;       // q | k | v of the query frame inside the attention core (wideblock.h)
         if (fuse_qkv) qkv = nullptr;
@@ -2163,6 +2220,7 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
         a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw;
         a.pt = pt; a.pl = plft; a.nWw = (W + pw) / 7; a.dilated = dil ? 1 : 0; a.ntile = ntile;
         { ProfScope ps(m, pname("wide_core", l), s); BDE_TRY(attn_tok16_launch(a, B, s)); }
+        }
         float* dst = (last && out) ? out : (x == ws.xa ? ws.xb : ws.xa);     // out == nullptr: the caller only wants out_nchw
         // x1 = shortcut + proj(attn)   (uncovered pixels of a dilated block: shortcut only; DTransformer.py:299, 79-82)
         // hidden = GELU(fc1(LN(x1))): with two-term operands both in one launch (projfc1_sb_kernel)
@@ -2271,18 +2329,26 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         if (!m->wide_fuse_qkv)
             BDE_TRY(run_tokgemm(m, "wide_qkv_all", l, al.blocks[0].qkvW, al.blocks[0].qkv, 3 * C, C, ws.mergedT[l], T * B, HW, ws.qkv0[l],
                                 nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+        // one refined neighbour (one negative buffer offset): its K | V are computed by the attention core of the frame that reads
+        // them (wide_core.h), from the neighbour's refined FRAG16 frame -- no K|V GEMM between two frames of the chain
+        int nneg = 0, neg_slot = -1;
+        for (int d = 0; d < D; ++d)
+            if (d != c.q_idx && c.buffer_index[d] < 0) { ++nneg; neg_slot = d; }
+        const bool in_core = wide_core2_ok(m, l) && nneg == 1;
         for (int t = 0; t < T; ++t) {
             const float* kvslot[BDE_MAX_FRAMES];
+            const float* prev_frag = nullptr;
             for (int d = 0; d < D; ++d) {
                 const int f = t + c.buffer_index[d];
                 if (d == c.q_idx || f < 0 || f >= T) kvslot[d] = nullptr;
+                else if (f < t && in_core) { kvslot[d] = nullptr; prev_frag = ws.mergedT[l] + (long)f * ffs; }
                 else if (f < t) kvslot[d] = ws.kvref[l] + (long)f * kvfs;      // refined (V5.py:166-169)
                 else kvslot[d] = ws.kvun[l] + (long)f * kvfs;
             }
             float* mtF = ws.mergedT[l] + (long)t * ffs;
             BDE_TRY(run_attention_frame_wide(m, l, mtF, kvslot, mtF, mtF, ws.merged[l] + (long)t * fs, B, H, W, 0, al.depth,
-                                             ws.qkv0[l] + (long)t * q0fs, s));
-            if (need_ref && t + 1 < T)
+                                             ws.qkv0[l] + (long)t * q0fs, s, prev_frag, neg_slot));
+            if (need_ref && !in_core && t + 1 < T)
                 BDE_TRY(run_tokgemm(m, "wide_kv", l, al.kvallW, al.kvall, al.depth * 2 * C, C, mtF, B, HW, ws.kvref[l] + (long)t * kvfs,
                                     nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
             if (on_frame) BDE_TRY(on_frame(m, t, ctx));
@@ -3047,6 +3113,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "wide_kv_sb") { m->wide_kv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_fuse_mlp") { m->wide_fuse_mlp = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_fuse_fc2") { m->wide_fuse_fc2 = (int)value; return BDE_OK; }
+    if (std::string(key) == "wide_core2") { m->wide_core2 = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") {
         if (m->conv_sb != (int)value)
             for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it
@@ -3119,6 +3186,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "wide_kv_sb") *value = m->wide_kv_sb;
     else if (k == "wide_fuse_mlp") *value = m->wide_fuse_mlp;
     else if (k == "wide_fuse_fc2") *value = m->wide_fuse_fc2;
+    else if (k == "wide_core2") *value = m->wide_core2;
     else if (k == "sb_terms") *value = m->sb_terms;
     else if (k == "sb_auto") *value = m->sb_auto;
     else if (k == "sb_overflows") *value = m->sb_overflows;       // forwards settled so far whose two-term operands left fp16's range
@@ -3483,19 +3551,27 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
         Workspace& w = m->W();
         const int C = al.C;
         const long ffs = (long)B * cdivl(HW, 16) * 16 * C;
+        int nneg = 0;
+        for (int d = 0; d < D; ++d) nneg += d != c.q_idx && c.buffer_index[d] < 0;
+        const bool in_core = wide_core2_ok(m, level) && nneg == 1;
+        const float* prev_frag = nullptr;
+        int prev_slot = -1;
         for (int d = 0; d < D; ++d) {
             kvslot[d] = nullptr;
             if (bufs[d] == nullptr) continue;
             float* fr = w.mergedT[level] + (long)d * ffs;
             BDE_TRY(nchw_to_frag(bufs[d], fr, B, C, (int)HW, s));
             if (d == c.q_idx) continue;
+            // as in the forward: the one frame at a negative offset goes to the attention core as it is (wide_core.h)
+            if (in_core && c.buffer_index[d] < 0) { prev_frag = fr; prev_slot = d; continue; }
             float* dst = w.kvun[level] + (long)d * kvfs;
             BDE_TRY(run_tokgemm(m, "wide_kv", level, al.kvallW, al.kvall, al.depth * 2 * C, C, fr, B, HW, dst, nullptr, ACT_NONE, nullptr,
                                 nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
             kvslot[d] = dst;
         }
         float* qf = w.mergedT[level] + (long)c.q_idx * ffs;
-        return run_attention_frame_wide(m, level, qf, kvslot, nullptr, nullptr, out, B, H, W, first_block, nblocks, nullptr, s);
+        return run_attention_frame_wide(m, level, qf, kvslot, nullptr, nullptr, out, B, H, W, first_block, nblocks, nullptr, s, prev_frag,
+                                        prev_slot);
     }
     for (int d = 0; d < D; ++d) {
         kvslot[d] = nullptr;

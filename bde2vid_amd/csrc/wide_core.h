@@ -1,0 +1,311 @@
+// Level-2 attention chain (head_dim 16, wideblock.h): the window half of a block -- q | k | v of the query frame's window tokens,
+// K | V of the REFINED neighbour frame's window tokens, softmax(q k^T + bias) v per (window, head) -- as one launch, second
+// generation of attn_tok16_kernel<true, true> (DTransformer.py:165-207; V5.py:154-169).
+//
+// What changed, and why (attn_tok16_kernel measured 15.9 us per launch for ~1 us of matrix work):
+//   * the head's q | k | v weight fragments (48 KB, two fp16 terms) come ONCE per workgroup, by LDS-DMA, all of them requested in
+//     the first instructions of the kernel together with every other operand (token fragments, bias tile, the other frames' K | V
+//     rows): one L2 round trip for everything instead of four register double-buffer rounds per wave, each wave re-fetching the
+//     same 48 KB;
+//   * the relative-position bias arrives as the score tiles' C operands (16-byte loads of a pre-packed table, as winblock.h)
+//     instead of 40 strided dword loads per lane;
+//   * K | V of the frame refined just before (buffer offset < 0, V5.py:166-169) are computed HERE from that frame's block output --
+//     norm_kv and the kv projection are the query frame's own k | v rows (DTransformer.py:183-190), so the neighbour's window
+//     tokens are one more token tile for fragments that are in LDS anyway -- which removes the K|V GEMM launch (26 us, 15 per
+//     forward) that sat between two frames of the sequential chain and its [T][HW][depth 2C] buffer.
+// Frames at offsets > 0 are still unrefined when they are needed: their K | V of all blocks come from one T-batched GEMM
+// (tokgemm_sb_kernel) as before.  Same arithmetic as attn_tok16_kernel<true, true>: two-term q|k|v GEMM, fp32 scores / softmax / p v.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wideblock.h"
+
+namespace bde {
+
+struct WideCoreArgs {
+    const float* x;               // FRAG16 [B][ntile][C/16][256]: block input of the query frame
+    const float* xp;              // FRAG16: the refined neighbour frame (slot p_slot), nullptr = none handled here
+    long x_bs;
+    int q_slot, p_slot;           // buffer slots (key ranges slot * 49 ..) of the two
+    const float* kv[ATT_MAXD];    // other slots: token-major rows holding K at +k_off[d], V at +v_off[d]; nullptr = zero frame
+    long kv_bs[ATT_MAXD];
+    int kv_ld[ATT_MAXD], k_off[ATT_MAXD], v_off[ATT_MAXD];
+    const float* kvpad;           // [2C] K | V of a zero token
+    const float* biasW;           // [heads][4 query tiles][10 key tiles][64 lanes][4]: score-tile C operands, keys slot-major, log2(e) folded
+    const unsigned short* wqkvS;  // q|k|v rows as two fp16 terms, k in FRAG16 group-pair order (TokGemmArgs::wS)
+    const float* wqkv_unscale;
+    const float *bqkv, *sqkv;     // [3C] folded biases / row sums of the LayerNorm-folded weights
+    float* out;                   // FRAG16 [B][ntile][C/16][256]: attention output
+    int D, C, heads, H, W, Hp, Wp, pt, pl, nWw, dilated, ntile;
+    unsigned* ovf;                // range guard of the two-term format (split.h)
+    unsigned long long* stamps;   // diagnostics only
+};
+#define WC_STAMP(i)                                                                                                  \
+    do {                                                                                                             \
+        if (a.stamps && lane == 0 && blockIdx.z == 0 && blockIdx.y == 0 && blockIdx.x < 16)                           \
+            a.stamps[(blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
+    } while (0)
+
+constexpr int WC_WL_BYTES = 3 * 8 * 2 * 1024;
+constexpr int WC_LDS_BYTES = WC_WL_BYTES + (2 * 10 * 16 * 16 + 2 * 48) * 4;      // 68.5 KB: two workgroups per CU
+
+// C = 256 (8 k-steps of 32), head_dim 16, D * 49 <= 160 keys.  grid (windows, heads, B), 256 threads = four query tiles.
+template <bool PREV>
+__global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a) {
+    constexpr int HD = 16, NT = 10, NKS = 8;
+    extern __shared__ __align__(16) unsigned char wc_lds[];
+    unsigned char* WL = wc_lds;                                       // weight fragments [q | k | v][k-step][term][64 lanes][16 B]
+    float* KL = reinterpret_cast<float*>(wc_lds + WC_WL_BYTES);       // [NT][HD][16 keys]
+    float* VL = KL + NT * HD * 16;                                    // [NT * 16 keys][HD]
+    float* PR = VL + NT * 16 * HD;                                    // folded bias | row sums of the head's q, k, v rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g4 = lane >> 4, col = lane & 15;
+    const int win = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int wi = win / a.nWw, wj = win - wi * a.nWw;
+    const int step = a.dilated ? 2 : 1;
+    const int c0 = head * HD;
+    const int nkey = a.D * ATT_TOK;
+    WC_STAMP(0);
+    auto token_pixel = [&](int tok) {
+        const int ta = tok / ATT_WS, tb = tok - ta * ATT_WS;
+        const int rp = wi * ATT_WS + ta * step, cp = wj * ATT_WS + tb * step;
+        const int ry = rp - a.pt, rx = cp - a.pl;
+        return (rp < a.Hp && cp < a.Wp && ry >= 0 && ry < a.H && rx >= 0 && rx < a.W) ? ry * a.W + rx : -1;
+    };
+    const int qi = wave * 16 + col;
+    const int qpix = qi < ATT_TOK ? token_pixel(qi) : -1;
+    const int ngk = a.C >> 4;
+
+    // ---- every operand of the launch is requested here ---------------------------------------------------------------------------
+    const long xo = ((long)(max(qpix, 0) >> 4) * ngk) * 64 + (max(qpix, 0) & 15) + 16 * g4;
+    const wf4* xw = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + xo;
+    // (token fragments: a rolling window of LA k-steps per token set is in flight -- all sixteen k-steps of both sets from the
+    //  start are 128 registers, which with two workgroups per CU is more than a wave has)
+    constexpr int LA = 4;
+    const wf4* xpw = PREV ? reinterpret_cast<const wf4*>(a.xp + b * a.x_bs) + xo : xw;
+    wf4 xq[2 * NKS], xpv[PREV ? 2 * NKS : 1];
+#pragma unroll
+    for (int kg = 0; kg < 2 * LA; ++kg) {
+        xq[kg] = xw[kg * 64];
+        if constexpr (PREV) xpv[kg] = xpw[kg * 64];
+    }
+    {
+        // weight fragments: 48 blocks of 1 KiB, twelve per wave; fragment (r, ks, t) of the packed rows: row tile r * ngk + head
+        const sb8* wsrc = reinterpret_cast<const sb8*>(a.wqkvS) + lane;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int f = wave * 12 + i;
+            const int r = f / (2 * NKS), rem = f - r * 2 * NKS;      // rem = ks * 2 + t
+            const sb8* src = wsrc + (((long)(r * ngk + head) * NKS * 2) + rem) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(WL + f * 1024), 16, 0, 0);
+        }
+    }
+    // K | V rows of the keys whose rows are not computed here -- the slots that are neither the query frame's nor the refined
+    // neighbour's, and the padding keys beyond D * 49 (rows of a zero token, as zero frames and padding pixels): token-major
+    // gathers, thread = (key, 4-channel piece).  GK keys: 62 with the neighbour in the core (one pass), 111 without (two).
+    constexpr int GK = NT * 16 - (PREV ? 2 : 1) * ATT_TOK, GIT = (GK * 4 + 255) / 256;
+    const int s_lo = PREV ? min(a.q_slot, a.p_slot) : a.q_slot, s_hi = PREV ? max(a.q_slot, a.p_slot) : a.q_slot;
+    auto gather_key = [&](int item) {                                 // item -> key index u, skipping the slots computed here
+        int u = item >> 2;
+        if (u >= s_lo * ATT_TOK) u += ATT_TOK;
+        if (PREV && u >= s_hi * ATT_TOK) u += ATT_TOK;
+        return u;
+    };
+    wf4 kk[GIT], vv[GIT];
+#pragma unroll
+    for (int t = 0; t < GIT; ++t) {
+        const int item = min(tid + t * 256, GK * 4 - 1);
+        const int u = gather_key(item), cg = item & 3;
+        const int d = min(u / ATT_TOK, a.D - 1), tok = u - (u / ATT_TOK) * ATT_TOK;
+        const int pix = u < nkey ? token_pixel(tok) : -1;
+        const float* kp = u < nkey ? a.kv[d] : nullptr;
+        const bool use = pix >= 0 && kp != nullptr;
+        const float* ksrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.k_off[d] + c0 + cg * 4 : a.kvpad + c0 + cg * 4;
+        const float* vsrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.v_off[d] + c0 + cg * 4 : a.kvpad + a.C + c0 + cg * 4;
+        kk[t] = *reinterpret_cast<const wf4*>(ksrc);
+        vv[t] = *reinterpret_cast<const wf4*>(vsrc);
+    }
+    if (tid < 24) {                                                   // bias and row sums of rows c0 .. c0 + 15 of q, k, v
+        const int which = tid / 12, i = tid - which * 12, r = i >> 2, q4 = i & 3;
+        const float* src = (which ? a.sqkv : a.bqkv) + r * a.C + c0 + q4 * 4;
+        *reinterpret_cast<float4*>(PR + which * 48 + r * 16 + q4 * 4) = *reinterpret_cast<const float4*>(src);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // one round trip for all of the above
+    __syncthreads();
+    WC_STAMP(1);
+
+    // ---- q | k | v of this wave's token tile (query frame) and k | v of the same window tokens of the refined neighbour -------------
+    f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq, akp = aq, avp = aq;
+    float s1 = 0.f, s2 = 0.f, p1 = 0.f, p2 = 0.f, gm = 0.f;
+    auto split_tile = [&](wf4 x0, wf4 x1, float& u1, float& u2, sb8 (&bfr)[2]) {
+        if (qpix < 0) x0 = x1 = wf4{0.f, 0.f, 0.f, 0.f};               // a zero token: LayerNorm(0) = beta, i.e. the folded bias alone
+        u1 += ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+        u2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+              ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
+        unsigned t[4][2];
+        ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
+        ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
+        ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
+        ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+        // (pins the running sums here: left free, the compiler sinks both chains of adds below the loop -- nothing needs them
+        //  earlier -- and keeps the eight fp32 values of every k-step alive for it: 64 registers per token set)
+        asm volatile("" : "+v"(u1), "+v"(u2), "+v"(gm));
+    };
+    // The relative-position bias of this wave's score tiles (their C operands as 16-byte loads of the pre-packed table) is
+    // requested half-way through the contraction: by then half of the token fragments' registers are free again, and the scores
+    // are still a microsecond away.  Held from the start it costs 40 registers through the GEMM phase.
+    f32x4 sc[NT];
+    const f32x4* biasp = reinterpret_cast<const f32x4*>(a.biasW) + ((long)(head * 4 + wave) * NT) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);                             // (keeps the loads and LDS reads of later k-steps out of this one)
+        if (ks + LA < NKS) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xq[2 * (ks + LA) + h] = xw[(2 * (ks + LA) + h) * 64];
+                if constexpr (PREV) xpv[2 * (ks + LA) + h] = xpw[(2 * (ks + LA) + h) * 64];
+            }
+        }
+        if (ks == NKS / 2) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sc[j] = biasp[j * 64];
+        }
+        sb8 fq[2], fk[2], fv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fq[t] = *reinterpret_cast<const sb8*>(WL + ((0 * NKS + ks) * 2 + t) * 1024 + lane * 16);
+            fk[t] = *reinterpret_cast<const sb8*>(WL + ((1 * NKS + ks) * 2 + t) * 1024 + lane * 16);
+            fv[t] = *reinterpret_cast<const sb8*>(WL + ((2 * NKS + ks) * 2 + t) * 1024 + lane * 16);
+        }
+        sb8 bq[2];
+        split_tile(xq[2 * ks], xq[2 * ks + 1], s1, s2, bq);
+        aq = sb_mma16<2>(fq, bq, aq);
+        ak = sb_mma16<2>(fk, bq, ak);
+        av = sb_mma16<2>(fv, bq, av);
+        if constexpr (PREV) {
+            sb8 bp[2];
+            split_tile(xpv[2 * ks], xpv[2 * ks + 1], p1, p2, bp);
+            akp = sb_mma16<2>(fk, bp, akp);
+            avp = sb_mma16<2>(fv, bp, avp);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    sb_guard_flush(gm, a.ovf);
+    WC_STAMP(2);
+    wf4 qv;
+    {
+        const float us = a.wqkv_unscale[0];
+        auto stats = [&](float u1, float u2, float& mean, float& rstd) {
+            u1 += __shfl_xor(u1, 16); u2 += __shfl_xor(u2, 16);
+            u1 += __shfl_xor(u1, 32); u2 += __shfl_xor(u2, 32);
+            mean = u1 / (float)a.C;
+            rstd = __builtin_amdgcn_rsqf(fmaxf(u2 / (float)a.C - mean * mean, 0.f) + 1e-5f);
+        };
+        float mean, rstd;
+        stats(s1, s2, mean, rstd);
+        float kq[4], vq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g4 + r;
+            qv[r] = rstd * (aq[r] * us - mean * PR[48 + i]) + PR[i];
+            kq[r] = rstd * (ak[r] * us - mean * PR[48 + 16 + i]) + PR[16 + i];
+            vq[r] = rstd * (av[r] * us - mean * PR[48 + 32 + i]) + PR[32 + i];
+        }
+        if (qi < ATT_TOK) {
+            // key index of this token in the slot-major key order; K row (k-step e = r, lanes g4) and the V row of the core below
+            const int u = a.q_slot * ATT_TOK + qi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) KL[((u >> 4) * HD + r * 4 + g4) * 16 + (u & 15)] = kq[r];
+            *reinterpret_cast<wf4*>(VL + u * HD + g4 * 4) = wf4{vq[0], vq[1], vq[2], vq[3]};
+        }
+        if constexpr (PREV) {
+            float meanp, rstdp;
+            stats(p1, p2, meanp, rstdp);
+            if (qi < ATT_TOK) {
+                const int u = a.p_slot * ATT_TOK + qi;
+                float vp[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * g4 + r;
+                    KL[((u >> 4) * HD + r * 4 + g4) * 16 + (u & 15)] = rstdp * (akp[r] * us - meanp * PR[48 + 16 + i]) + PR[16 + i];
+                    vp[r] = rstdp * (avp[r] * us - meanp * PR[48 + 32 + i]) + PR[32 + i];
+                }
+                *reinterpret_cast<wf4*>(VL + u * HD + g4 * 4) = wf4{vp[0], vp[1], vp[2], vp[3]};
+            }
+        }
+    }
+    if (qpix < 0) qv = wf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < GIT; ++t) {
+        const int item = tid + t * 256;
+        if (item >= GK * 4) continue;
+        const int u = gather_key(item), cg = item & 3;
+        // channel cg*4 + e of the head is contracted at k-step e by the lanes g4 = cg: LDS row e*4 + cg
+#pragma unroll
+        for (int e = 0; e < 4; ++e) KL[((u >> 4) * HD + e * 4 + cg) * 16 + (u & 15)] = kk[t][e];
+        *reinterpret_cast<wf4*>(VL + u * HD + cg * 4) = vv[t];
+    }
+    __syncthreads();
+    WC_STAMP(3);
+    // ---- scores^T = k q^T + bias, softmax over the keys, out^T = v^T p^T (attn_mfma.h) ---------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            sc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(KL[(j * HD + ks * 4 + g4) * 16 + col], qv[ks], sc[j], 0, 0, 0);
+    float mx = sc[0][0];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        mx = fmaxf(mx, fmaxf(sc[j][0], sc[j][1]));
+        mx = fmaxf(mx, fmaxf(sc[j][2], sc[j][3]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    WC_STAMP(4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        float p[4], va[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(sc[j][r] - mx);
+            va[r] = VL[(j * 16 + g4 * 4 + r) * HD + col];
+            l += p[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r], p[r], acc, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    WC_STAMP(5);
+    if (qpix >= 0) {
+        const float inv = 1.f / l;
+        // rows of acc = channels c0 + 4 g4 + r of query pixel qpix: FRAG16 group `head`, lane (pixel column + 16 r), element g4
+        float* op = a.out + b * a.x_bs + ((long)(qpix >> 4) * ngk + head) * 256 + (qpix & 15) * 4 + g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[r * 64] = acc[r] * inv;
+    }
+    WC_STAMP(6);
+}
+
+static int wide_core_launch(const WideCoreArgs& a, int B, hipStream_t s) {
+    if (a.C != 256 || a.heads * 16 != a.C || a.D * ATT_TOK > 160)
+        return fail(BDE_ERR_UNSUPPORTED, "wide attention core: C = %d, %d heads, D = %d", a.C, a.heads, a.D);
+    const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
+    static unsigned char raised1[BDE_MAX_DEVICES], raised0[BDE_MAX_DEVICES];
+    if (a.xp) {
+        BDE_HIP(raise_dynamic_lds(raised1, (const void*)wide_core_kernel<true>, WC_LDS_BYTES));
+        hipLaunchKernelGGL(wide_core_kernel<true>, dim3(nW, a.heads, B), dim3(256), WC_LDS_BYTES, s, a);
+    } else {
+        BDE_HIP(raise_dynamic_lds(raised0, (const void*)wide_core_kernel<false>, WC_LDS_BYTES));
+        hipLaunchKernelGGL(wide_core_kernel<false>, dim3(nW, a.heads, B), dim3(256), WC_LDS_BYTES, s, a);
+    }
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
+}  // namespace bde

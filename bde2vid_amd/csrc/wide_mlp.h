@@ -86,10 +86,15 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     WM_STAMP(0);
 
     // ---- operands that do not depend on anything computed here: all requested before the first MFMA ------------------------------
+    // Every workgroup of a launch streams the same weight bytes (all of them proj, the 44 of a quarter its fc1 / fc2 rows) and
+    // the workgroups run in lockstep: walking K in the same order they would all ask the same L2 channel for the same lines at the
+    // same time.  Each workgroup therefore starts its K loop at a k-step of its own (`rot`, order rot, rot + 1, ... mod 8): the
+    // sum over K is the same set of products in a rotated order -- fixed per workgroup, so results stay bit-reproducible.
+    const int rot = __builtin_amdgcn_readfirstlane((tile + 3 * quarter) & (NKS - 1));
     const wf4* ap = reinterpret_cast<const wf4*>(a.ao + b * a.x_bs) + ((long)tile * 16) * 64 + lane;
-    wf4 aov[16];
+    wf4 aov[16];                           // aov[2 j], aov[2 j + 1]: the operand of k-step (j + rot) mod 8
 #pragma unroll
-    for (int kg = 0; kg < 16; ++kg) aov[kg] = ap[kg * 64];
+    for (int kg = 0; kg < 16; ++kg) aov[kg] = ap[((kg + 2 * rot) & 15) * 64];
     float xr[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -110,7 +115,8 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     sb8 ring[RING][4][2];
     auto fetch = [&](auto Gc) {
         constexpr int G = decltype(Gc)::value;
-        constexpr int ph = G / NKS, ks = G % NKS;
+        constexpr int ph = G / NKS;
+        const int ks = (G % NKS + rot) & (NKS - 1);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -153,8 +159,9 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
             for (int q = 0; q < 2; ++q) bfr[q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
         } else {
             const unsigned char* base = ph == 1 ? X1S : HS;
+            const int kr = (ks + rot) & (NKS - 1);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) bfr[q] = *reinterpret_cast<const sb8*>(base + ((ks * 2 + q) * 64 + lane) * 16);
+            for (int q = 0; q < 2; ++q) bfr[q] = *reinterpret_cast<const sb8*>(base + ((kr * 2 + q) * 64 + lane) * 16);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = sb_mma16<2>(ring[G % RING][m], bfr, acc[m]);
