@@ -760,10 +760,16 @@ struct bde_model {
     // optional HIP-event timing of tagged launches / stages (bde_profile_*)
     // side stream: per-frame work that only depends on already-refined frames (next level's encoder /
     // gate convs, or the decoder) runs beside the sequential attention chain
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> frame_ev;
-    hipEvent_t join_ev = nullptr;
-    int overlap = 0;              // measured neutral-to-negative at config A (contention slows the chain): off
+    // one set per workspace slot for eager forwards, and one more (index MAX_SLOTS) used only while a graph is being captured: a
+    // stream that still holds eager work of an earlier call cannot join a capture
+    hipStream_t side[MAX_SLOTS + 1] = {};
+    std::vector<hipEvent_t> frame_ev[MAX_SLOTS + 1];
+    hipEvent_t join_ev[MAX_SLOTS + 1] = {};
+    int overlap = 0;              // 1: decoder of the frames already refined beside the last level's attention chain, a forked branch
+                                  // of the captured graph (forward_body).  Bit-identical frames; measured on one box, config A: 1098 vs
+                                  // 2179 frames/s with three sequences in flight, 1459 vs 1701 with one -- a hipGraph with a fork does
+                                  // not replay as one batch of packets on ROCm 7.2: off
+    int eager_cut = 1;            // default mode: head + first encoder convolution and the last convolution launched outside the graph (forward_on)
     int overlap_chunk = 4;        // frames handed to the side stream per launch set
     int debug_skip = 0;           // diagnostic what-if timing only (results are wrong): bit0 attention level 0, bit1 attention levels >= 1,
                                   // bit2 recurrent steps, bit3 decoder, bit4 encoder + gate convs
@@ -1296,6 +1302,8 @@ struct ConvCall {
     float* out_sb = nullptr;     // store the result as SB16 here INSTEAD of fp32 planes in `out` (conv_mfma.h sb_out)
     long out_sb_gs = 0;          // its group stride, floats
     bool in_sb = false;          // `in` already is the SB16 image (in_gs in floats of that image): conv_sb or fail
+    int decide_N = 0;            // > 0: choose the kernel as for a launch of this many frames (a chunk of a batched launch computes
+                                 // exactly what the whole launch computes for its frames)
 };
 
 // Will run_conv take the split-bf16 kernels for this layer at this size?  (decided before the producer of its input runs)
@@ -1361,7 +1369,7 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     //  5x5: decoder 0 488 vs 633, decoder 1 (64 channels) 502 vs 641, encoder 1 / 2 (stride 2) 271 / 300 vs 345 / 335;
     //  conv_sb_pick has no shape for 32 output channels or for the stride-2 halo of level 0, those stay on the fp32 kernels)
     // (the fused predI epilogue needs every output channel of a pixel in one wave: 32 channels)
-    if (cc.in_sb || ((!cc.pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, cc.stride, cc.N, cc.Hs, cc.Ws))) {
+    if (cc.in_sb || ((!cc.pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, cc.stride, cc.decide_N > 0 ? cc.decide_N : cc.N, cc.Hs, cc.Ws))) {
         // split the input into three bf16 terms (SB16) unless its producer already wrote it that way, then the convolution
         // on the bf16 matrix cores; the small launches (a few frames of a small map) stay on the fp32 kernels
         Workspace& ws = const_cast<bde_model*>(m)->W();
@@ -2427,17 +2435,19 @@ static int run_bottleneck_level(bde_model* m, int l, int T, int B, int h, int w,
     return BDE_OK;
 }
 
-// Parts of a forward (forward_on): PART_MAIN = everything up to and including the last kernel that writes split operands,
-// PART_TAIL = what follows it -- the last decoder's convolution (+ predI).  The overflow word of the range guard (split.h) is
-// read back between the two, so the host learns about an overflow while the tail still runs.
-enum { PART_ALL = 0, PART_MAIN = 1, PART_TAIL = 2 };
+// Parts of a forward (forward_on): PART_PRE = head and the first level's encoder convolution, PART_MAIN = everything between it and
+// the last kernel that writes split operands (the captured graph), PART_TAIL = what follows that kernel -- the last decoder
+// convolution (+ predI) of the frames decoded last.  The overflow word of the range guard (split.h) is read back in front of the
+// tail, so the host learns about an overflow while the tail still runs; PART_ALL = the whole forward in one piece.
+enum { PART_ALL = 0, PART_MAIN = 1, PART_TAIL = 2, PART_PRE = 3 };
 
 static int run_decoder(bde_model* m, int j, const float* in, const float* skip, float* out, int N, int Hs, int Ws,
-                       hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr, int part = PART_ALL) {
+                       hipStream_t s, const float* pred_head = nullptr, float* pred_out = nullptr, int part = PART_ALL, int decide_N = 0) {
     const PackedLayer& pl = m->dec[j];
     Workspace& ws = m->W();
+    if (decide_N <= 0) decide_N = N;
     // a split-bf16 convolution reads SB16: the upsampling kernel then writes that image directly (no fp32 map, no conversion)
-    const bool to_sb = m->fuse_enc_sb && (!pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, 1, N, 2 * Hs, 2 * Ws) && ws.sb &&
+    const bool to_sb = m->fuse_enc_sb && (!pred_out || pl.Cout <= 32) && conv_takes_sb(m, pl, 1, decide_N, 2 * Hs, 2 * Ws) && ws.sb &&
                        split_bf16_bytes(N, pl.Cin, 4L * Hs * Ws) <= ws.sb_bytes;
     if (part != PART_TAIL) {
         ProfScope ps(m, pname("dec_up", j), s);
@@ -2456,6 +2466,7 @@ static int run_decoder(bde_model* m, int j, const float* in, const float* skip, 
     d.act = ACT_RELU6;
     d.pred_head = pred_head;
     d.pred_out = pred_out;
+    d.decide_N = decide_N;
     ProfScope ps(m, pname("dec_conv", j), s);
     return run_conv(m, d, s);
 }
@@ -2611,12 +2622,15 @@ static int forward_on(bde_model* m, const float* const* events, int T, int B, in
     // Range guard (split.h): the slot's overflow word starts at zero and is read back behind the last kernel that writes split
     // operands -- in front of the forward's tail where the tail is a launch of its own (no side-stream decode, the upsampling
     // kernel writes the last convolution's operand image itself), behind it otherwise.
+    // In the default mode (one sequence in flight) the host waits for that word before bde_forward returns: the forward is then
+    // cut in three -- head + first encoder convolution launched eagerly (PART_PRE: the chip has work while the host replays the
+    // graph), the graph (PART_MAIN), the last convolution launched eagerly behind the read-back (PART_TAIL).
     const bool guard = m->ovf() != nullptr;
-    const bool side_decode = m->overlap != 0 && m->pipeline < 2;
-    const bool cut = guard && !side_decode && m->fuse_enc_sb && !(m->debug_skip & 8);
+    const bool cut = guard && m->eager_cut && m->pipeline < 2 && m->fuse_enc_sb && !(m->debug_skip & (8 | 16)) && !m->prof_on;
     const int part_main = cut ? PART_MAIN : PART_ALL;
     if (guard) BDE_HIP(hipMemsetAsync(m->ovf(), 0, sizeof(unsigned), s));
-    const bool can_graph = m->use_graph && !side_decode && ws.warm;   // (profiling spans are captured as event-record nodes)
+    if (cut) BDE_TRY(forward_body(m, T, B, H, W, s, PART_PRE));
+    const bool can_graph = m->use_graph && ws.warm;   // (profiling spans are captured as event-record nodes)
     if (ws.graph_exec && ws.graph_part != part_main) { (void)hipGraphExecDestroy(ws.graph_exec); ws.graph_exec = nullptr; }
     if (can_graph && !ws.graph_exec) {
         // capture on a private stream (the caller's may be the legacy default stream, which cannot
@@ -2676,7 +2690,7 @@ static int decode_frames(bde_model* mm, int f0, int nf, int T_, int B_, int H_, 
             BDE_TRY(run_decoder(mm, j, x, skip, w.dec[j] + (long)f0 * out_fs, nf,
                                 H_ >> (l + 1), W_ >> (l + 1), st,
                                 fuse ? w.head + (long)f0 * mm->cfg.basechannels * H_ * W_ : nullptr,
-                                fuse ? w.out + (long)f0 * H_ * W_ : nullptr, jpart));
+                                fuse ? w.out + (long)f0 * H_ * W_ : nullptr, jpart, T_ * B_));
         }
         x = w.dec[j] + (long)f0 * out_fs;
     }
@@ -2704,74 +2718,83 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s,
     Workspace& ws = m->W();
     const int L = c.num_encoders;
     const long TB = (long)T * B;
-    if (part == PART_TAIL) return (m->debug_skip & 8) ? BDE_OK : decode_frames(m, 0, (int)TB, T, B, H, W, s, PART_TAIL);
-    // A. head (V5.py:116)
-    ConvCall hc;
-    hc.pl = &m->head;
-    hc.in = ws.ev;
-    hc.out = ws.head;
-    hc.N = (int)TB;
-    hc.Hs = H;
-    hc.Ws = W;
-    hc.act = ACT_RELU;
-    { ProfScope ps(m, "head", s); BDE_TRY(run_conv(m, hc, s)); }
-    // B. levels (V5.py:119-172).  While the attention chain of a level walks the frames one by one
-    //    (V5.py:154-169), everything that depends only on frames already refined runs on a side
-    //    stream: the next level's encoder + gate convs, or (last level) the decoder.
-    struct SideCtx { int l, T, B, H, W; hipStream_t main, side; bool last; int chunk; };
-    static auto decode_fn = decode_frames;     // (plain function pointer for the captureless side-stream callback)
-    const bool plain_flags = c.use_rc && c.recurrent_type == 0 && !c.skip_concat && c.depths[c.num_encoders - 1] > 0;
-    const bool overlap = m->overlap != 0 && m->pipeline < 2 && plain_flags;   // the side stream and its events are per model, not per slot
-    if (overlap && !m->side) {
+    // While the attention chain of the LAST level walks the frames one by one (V5.py:154-169), the decoder of the frames already
+    // refined -- independent per frame, V5.py:183-202 -- runs on a side stream in chunks of `overlap_chunk` frames: a forked branch
+    // of the captured graph.  The chain's launches are latency-bound and leave most of the chip idle; the decoder's are not.  The
+    // last chunk stays on the main stream (it is what the forward's tail is cut from).  Results are bit-identical: same launches.
+    const bool plain_flags = c.use_rc && c.recurrent_type == 0 && !c.skip_concat && c.depths[L - 1] > 0;
+    const bool side_decode = m->overlap != 0 && plain_flags && !(m->debug_skip & (2 | 8)) && !m->prof_on && T > m->overlap_chunk;
+    const int last_chunk_t0 = side_decode ? (T - 1) / m->overlap_chunk * m->overlap_chunk : 0;
+    const int tail_f0 = last_chunk_t0 * B, tail_nf = (int)TB - tail_f0;
+    if (part == PART_TAIL) return (m->debug_skip & 8) ? BDE_OK : decode_frames(m, tail_f0, tail_nf, T, B, H, W, s, PART_TAIL);
+    // A. head (V5.py:116) and the first level's encoder convolution: PART_PRE
+    if (part != PART_MAIN) {
+        ConvCall hc;
+        hc.pl = &m->head;
+        hc.in = ws.ev;
+        hc.out = ws.head;
+        hc.N = (int)TB;
+        hc.Hs = H;
+        hc.Ws = W;
+        hc.act = ACT_RELU;
+        { ProfScope ps(m, "head", s); BDE_TRY(run_conv(m, hc, s)); }
+        if (!(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, 0, ws.head, 0, (int)TB, T, B, H, W, s));
+        if (part == PART_PRE) return BDE_OK;
+    }
+    // B. levels (V5.py:119-172)
+    struct SideCtx { int T, B, H, W, chunk, slot; hipStream_t main, side; };
+    static auto decode_fn = decode_frames;     // (plain function pointer for the captureless callback)
+    const int slot = (m->cap_stream && s == m->cap_stream) ? bde_model::MAX_SLOTS : m->cur;   // (capturing: the capture-only set)
+    if (side_decode && !m->side[slot]) {
         int lo = 0, hi = 0;                               // lowest priority: the chain on the main stream goes first
         BDE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        BDE_HIP(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, lo));
-        BDE_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
+        BDE_HIP(hipStreamCreateWithPriority(&m->side[slot], hipStreamNonBlocking, lo));
+        BDE_HIP(hipEventCreateWithFlags(&m->join_ev[slot], hipEventDisableTiming));
     }
-    while (overlap && (int)m->frame_ev.size() < T) {
+    while (side_decode && (int)m->frame_ev[slot].size() < T) {
         hipEvent_t e;
         BDE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        m->frame_ev.push_back(e);
+        m->frame_ev[slot].push_back(e);
     }
     const float* target = ws.head;
-    bool enc_done = false, decoded = false;
+    bool decoded = false;
     for (int l = 0; l < L; ++l) {
         const int Hl = H >> l, Wl = W >> l, h = Hl / 2, w = Wl / 2, C = m->cout(l);
-        BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s, enc_done));
-        enc_done = false;
+        BDE_TRY(run_recurrent_level(m, l, target, T, B, Hl, Wl, s, /*enc_done=*/l == 0));
         const long n = TB * C * h * w;
         { ProfScope ps(m, pname("merge", l), s); BDE_TRY(add2(ws.hseq[l], ws.hseq[l] + n, ws.merged[l], n, s)); }   // V5.py:137-147
         if (c.depths[l] > 0 && !(m->debug_skip & (l == 0 ? 1 : 2))) {
             static const char* names[BDE_MAX_LEVELS] = {"attn0", "attn1", "attn2", "attn3", "attn4", "attn5", "attn6", "attn7"};
             ProfScope ps(m, names[l], s);
-            SideCtx sc{l, T, B, H, W, s, m->side, l == L - 1, m->overlap_chunk};
+            SideCtx sc{T, B, H, W, m->overlap_chunk, slot, s, m->side[slot]};
             FrameDoneFn fn = nullptr;
-            if (overlap) {
+            const bool fork = side_decode && l == L - 1;
+            if (fork) {
                 fn = [](bde_model* mm, int t, void* vp) -> int {
                     SideCtx* q = (SideCtx*)vp;
-                    // hand the refined frames to the side stream in chunks (bigger grids per launch)
                     const int done = t + 1;
-                    if (done % q->chunk != 0 && done != q->T) return BDE_OK;
-                    const int t0 = (done - 1) / q->chunk * q->chunk, nt = done - t0;
-                    BDE_HIP(hipEventRecord(mm->frame_ev[t], q->main));
-                    BDE_HIP(hipStreamWaitEvent(q->side, mm->frame_ev[t], 0));
-                    if (q->last) return decode_fn(mm, t0 * q->B, nt * q->B, q->T, q->B, q->H, q->W, q->side, PART_ALL);
-                    const int ln = q->l + 1;
-                    return run_enc_gx(mm, ln, mm->W().merged[q->l], t0 * q->B, nt * q->B, q->T, q->B, q->H >> ln, q->W >> ln, q->side);
+                    if (done % q->chunk != 0 || done > (q->T - 1) / q->chunk * q->chunk) return BDE_OK;   // (the last chunk: main stream)
+                    const int t0 = done - q->chunk;
+                    BDE_HIP(hipEventRecord(mm->frame_ev[q->slot][t], q->main));
+                    BDE_HIP(hipStreamWaitEvent(q->side, mm->frame_ev[q->slot][t], 0));
+                    return decode_fn(mm, t0 * q->B, q->chunk * q->B, q->T, q->B, q->H, q->W, q->side, PART_ALL);
                 };
             }
             BDE_TRY(run_attention_level(m, l, T, B, h, w, s, fn, &sc));
-            if (overlap) {
-                BDE_HIP(hipEventRecord(m->join_ev, m->side));
-                BDE_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
-                if (l == L - 1) decoded = true; else enc_done = true;
+            if (fork) {
+                BDE_HIP(hipEventRecord(m->join_ev[slot], m->side[slot]));
+                BDE_HIP(hipStreamWaitEvent(s, m->join_ev[slot], 0));
+                decoded = true;
             }
         }
         if (l == L - 1 && c.depths[l] == 0) BDE_TRY(run_bottleneck_level(m, l, T, B, h, w, s));
         target = ws.merged[l];
     }
-    if (!decoded && !(m->debug_skip & 8)) BDE_TRY(decode_frames(m, 0, (int)TB, T, B, H, W, s, part));
-    return BDE_OK;
+    if (m->debug_skip & 8) return BDE_OK;
+    // C. decoder: every frame, or the last chunk behind a forked decode; PART_MAIN stops in front of its last convolution
+    const int dpart = part == PART_MAIN ? PART_MAIN : PART_ALL;
+    if (decoded) return decode_frames(m, tail_f0, tail_nf, T, B, H, W, s, dpart);
+    return decode_frames(m, 0, (int)TB, T, B, H, W, s, dpart);
 }
 
 static int validate_config(const bde_config* c) {
@@ -2847,9 +2870,11 @@ void bde_destroy(bde_model* m) {
     }
     for (auto& sp : m->prof) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : m->prof_pool) (void)hipEventDestroy(e);
-    for (auto e : m->frame_ev) (void)hipEventDestroy(e);
-    if (m->join_ev) (void)hipEventDestroy(m->join_ev);
-    if (m->side) (void)hipStreamDestroy(m->side);
+    for (int i = 0; i <= bde_model::MAX_SLOTS; ++i) {
+        for (auto e : m->frame_ev[i]) (void)hipEventDestroy(e);
+        if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
+        if (m->side[i]) (void)hipStreamDestroy(m->side[i]);
+    }
     delete m;
 }
 
@@ -3159,6 +3184,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "tok_npt") { m->tune.tok_npt = (int)value; return BDE_OK; }
     if (std::string(key) == "tok_debug") { m->tok_debug = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap") { m->overlap = (int)value; return BDE_OK; }
+    if (std::string(key) == "eager_cut") { m->eager_cut = (int)value; return BDE_OK; }
     if (std::string(key) == "debug_skip") { m->debug_skip = (int)value; return BDE_OK; }
     if (std::string(key) == "overlap_chunk") { m->overlap_chunk = std::max<int>(1, (int)value); return BDE_OK; }
     return fail(BDE_ERR_ARG, "unknown tuning key '%s'", key);

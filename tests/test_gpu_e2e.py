@@ -633,3 +633,38 @@ def test_range_guard_error_path_and_serving_mode():
         assert torch.isfinite(o).all(), i
         # (sequences that ran before the switch keep their two-term frames: both formats are fp32-equivalent)
         assert maxabs(o, r) <= 2e-5, i
+
+
+def test_forked_decoder_is_bit_identical_to_the_serial_schedule():
+    """"overlap" = 1 (off by default: measured slower, a forked hipGraph does not replay as one batch on ROCm 7.2): the decoder of
+    the frames already refined runs in chunks of four on a forked branch of the captured graph beside the last level's attention
+    chain (V5.py:183-202 is independent per frame); the last chunk and the cut
+    into eager head / graph / eager tail around the range guard's read-back are part of the same schedule.  Every launch is the
+    launch of the serial schedule restricted to its frames: frames equal bit for bit, eager, captured and replayed, one sequence
+    in flight or three."""
+    from tests.util import golden_inputs
+    from bde2vid_amd import canonical
+    from bde2vid_amd.model import build_model
+    from bde2vid_amd.weights import formula_state_dict
+    cfg = canonical()
+    m = build_model(cfg, formula_state_dict(cfg), 'cuda:0')
+    for T in (10, 5):
+        xs = golden_inputs(T, 1, 5, 184, 240, 97531 + T)
+        inp = [{'events': torch.from_numpy(x).cuda()} for x in xs]
+        with torch.no_grad():
+            m.set_tuning('overlap', 0)
+            ref = torch.stack(m(inp)).clone()
+            ref2 = torch.stack(m(inp)).clone()            # second call of the shape: the captured graph
+            m.set_tuning('overlap', 1)
+            outs = [torch.stack(m(inp)).clone() for _ in range(3)]   # eager, capture, replay
+            m.set_tuning('pipeline', 3)
+            pip = [m(inp) for _ in range(7)]
+            m.wait()
+            torch.cuda.synchronize()
+            m.set_tuning('pipeline', 1)
+            m.set_tuning('overlap', 0)
+        assert torch.equal(ref, ref2)
+        for o in outs:
+            assert torch.equal(o, ref), T
+        for o in pip:
+            assert torch.equal(torch.stack(o), ref), T
