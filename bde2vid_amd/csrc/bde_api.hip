@@ -669,6 +669,7 @@ struct AttnBlock {
     long qkvHF = -1, qkvHF_unscale = -1;                      // q|k|v as two fp16 terms in FRAG16 k order (attn_tok16_kernel<true, true>)
     long projHF = -1, fc1HF = -1, mlpHF_unscale = -1;         // proj, fc1 likewise (projfc1_sb_kernel); unscale: {proj, fc1}
     long fc1N = -1, fc2N = -1, mlpN_unscale = -1;             // fc1, fc2 as two fp16 terms in natural k order (mlp_fused_kernel); unscale: {fc1, fc2}
+    long qkvN = -1, qkvN_unscale = -1;                        // q|k|v likewise (wide_core_kernel on SPL16 operands)
     long kvpad_off = -1;    // [2C]
     long bias_off = -1;     // [heads][D*49][49]
     long biasF_off = -1;    // the same bias in the score-tile order of winblock.h (64 channels, 16 heads only)
@@ -691,6 +692,9 @@ struct Workspace {
     std::vector<float*> xenc, gx, hseq, cst, merged, mergedT, kvun, kvref, dec, qkv0;
     float *qkv = nullptr, *ao = nullptr, *x1 = nullptr, *hid = nullptr, *xa = nullptr, *xb = nullptr;
     int* tile_count = nullptr;    // wide_mlp.h: per (batch, token tile) arrival counters of the fused MLP launch, zero between launches
+    // SPL16 twins (wide_core.h) of the frames of a head_dim-16 level and of the block intermediates, with their LayerNorm statistics
+    std::vector<float*> mergedS, mstats;
+    float *xaS = nullptr, *xbS = nullptr, *stA = nullptr, *stB = nullptr;
     float* up = nullptr;          // upsampled (+skip) decoder input, largest decoder
     float* sb = nullptr;          // split-bf16 image of the input of the convolution in flight (conv_sb.h)
     float* sb2 = nullptr;         // split-bf16 encoder output of a level, written by the encoder conv's epilogue for its gate conv
@@ -712,6 +716,8 @@ struct Workspace {
         // no pointer outlives its allocation: the op-level entry points test them (ws.sb, ws.hsk[l], ...) before use
         ev = head = out = qkv = ao = x1 = hid = xa = xb = up = sb = sb2 = cat = fuse = rbA = rbX[0] = rbX[1] = zero_l = nullptr;
         tile_count = nullptr;
+        xaS = xbS = stA = stB = nullptr;
+        mergedS.clear(); mstats.clear();
         sb_bytes = sb2_bytes = 0;
         for (auto* v : {&xenc, &gx, &hseq, &cst, &merged, &mergedT, &kvun, &kvref, &dec, &qkv0, &gur, &ghr, &gou, &gub, &hsk, &hsb, &ghb}) v->clear();
         T = B = H = W = 0;
@@ -795,6 +801,7 @@ struct bde_model {
     int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
     int wide_fuse_mlp = 1;        // ... and x1 = x + proj(.) together with GELU(fc1(LN(x1))) in one launch (projfc1_sb_kernel)
     int wide_fuse_fc2 = 1;        // ... and fc2 + both residuals in the same launch (mlp_fused_kernel, wide_mlp.h): two launches per block
+    int wide_spl = 1;             // ... on frames kept as SPL16 (pre-split operand fragments + LayerNorm statistics, wide_core.h)
     int wide_core2 = 1;           // the window half of such a block as wide_core_kernel (wide_core.h): weights by LDS-DMA, K | V of the
                                   // refined neighbour frame computed inside (no K|V GEMM launch between two frames)
     int wide_kv_sb = 1;           // K|V GEMMs of the head_dim-16 chain on two-term split operands (tokgemm_sb_kernel, wideblock.h)
@@ -1205,6 +1212,8 @@ static int build_packed(bde_model* m) {
                 ab.mlpN_unscale = ar.alloc(4);
                 ab.fc1N = pack16_split(ar, fc1.w.data(), hid, C, 2, ab.mlpN_unscale);
                 ab.fc2N = pack16_split(ar, fc2.w.data(), C, hid, 2, ab.mlpN_unscale + 1);
+                ab.qkvN_unscale = ar.alloc(4);
+                ab.qkvN = pack16_split(ar, qkv.w.data(), 3 * C, C, 2, ab.qkvN_unscale);
             }
             if (C == WB_C && heads == WB_NH && D <= WB_MAXD) {
                 ab.projS = pack16_split(ar, proj.w.data(), C, C, 3, -1);
@@ -1430,6 +1439,7 @@ static int ws_alloc(Workspace& ws, float** p, long numel) {
 
 static bool winblock_ok(const bde_model* m, int l);
 static bool wide_ok(const bde_model* m, int l);
+static bool wide_core2_ok(const bde_model* m, int l);
 static bool lstm_sb_ok(const bde_model* m, int l, int B, int h, int w);
 static bool lstm_sbk_ok(const bde_model* m, int l, int h, int w);
 static bool lstm_sbx_ok(const bde_model* m, int l, int h, int w);
@@ -1448,6 +1458,7 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
     ws.hsb.assign(L, nullptr); ws.ghb.assign(L, nullptr); ws.hsk.assign(L, nullptr);
     ws.gur.assign(L, nullptr); ws.ghr.assign(L, nullptr); ws.gou.assign(L, nullptr); ws.gub.assign(L, nullptr);
     const bool gru = c.use_rc && c.recurrent_type == 1;
+    ws.mergedS.assign(L, nullptr); ws.mstats.assign(L, nullptr);
     ws.merged.assign(L, nullptr); ws.mergedT.assign(L, nullptr); ws.kvun.assign(L, nullptr); ws.kvref.assign(L, nullptr); ws.dec.assign(L, nullptr); ws.qkv0.assign(L, nullptr);
     long max_attn = 0;
     for (int l = 0; l < L; ++l) {
@@ -1480,6 +1491,10 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
             } else if (wide_ok(m, l)) {
                 // fragment-layout twin of merged (token tiles of 16) + token-major K|V stacks and first-block q|k|v
                 BDE_TRY(ws_alloc(ws, &ws.mergedT[l], TB * C * hwp));
+                if (wide_core2_ok(m, l)) {                    // ... and its SPL16 twin + statistics (wide_core.h)
+                    BDE_TRY(ws_alloc(ws, &ws.mergedS[l], TB * C * hwp));
+                    BDE_TRY(ws_alloc(ws, &ws.mstats[l], TB * hwp * 2));
+                }
                 BDE_TRY(ws_alloc(ws, &ws.kvun[l], TB * c.depths[l] * 2 * C * hw));
                 BDE_TRY(ws_alloc(ws, &ws.kvref[l], TB * c.depths[l] * 2 * C * hw));
                 BDE_TRY(ws_alloc(ws, &ws.qkv0[l], TB * 3 * C * hw));
@@ -1533,6 +1548,10 @@ static int ensure_workspace(bde_model* m, int T, int B, int H, int W) {
         BDE_TRY(ws_alloc(ws, &ws.hid, 4 * max_attn));
         BDE_TRY(ws_alloc(ws, &ws.xa, max_attn));
         BDE_TRY(ws_alloc(ws, &ws.xb, max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.xaS, max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.xbS, max_attn));
+        BDE_TRY(ws_alloc(ws, &ws.stA, max_attn / 64 + 64));       // (two floats per token of at least 128 channels)
+        BDE_TRY(ws_alloc(ws, &ws.stB, max_attn / 64 + 64));
         float* cnt = nullptr;                              // one counter per 16 tokens of the largest attention frame
         BDE_TRY(ws_alloc(ws, &cnt, max_attn / 16 + 64));
         BDE_HIP(hipMemset(cnt, 0, sizeof(int) * (size_t)(max_attn / 16 + 64)));
@@ -2142,9 +2161,11 @@ static bool wide_core2_ok(const bde_model* m, int l) {
     return m->wide_core2 && m->wide_fuse_qkv && m->wide_kv_sb && m->sb_terms == 2 && al.C == 256 && m->cfg.num_heads * 16 == al.C &&
            al.depth > 0 && al.blocks[0].biasW_off >= 0 && al.blocks[0].qkvHF >= 0;
 }
+struct WideTwin { float* s = nullptr; float* st = nullptr; };     // SPL16 image (as float*) and statistics of a FRAG16 frame, or nothing
 static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const float* const* kvslot, const float* addres, float* out,
                                     float* out_nchw, int B, int H, int W, int blk0, int nblk, const float* qkv_first, hipStream_t s,
-                                    const float* prev_frag = nullptr, int prev_slot = -1) {
+                                    const float* prev_frag = nullptr, int prev_slot = -1, WideTwin xq_twin = WideTwin(),
+                                    WideTwin out_twin = WideTwin(), WideTwin prev_twin = WideTwin()) {
     const bde_config& c = m->cfg;
     Workspace& ws = m->W();
     const AttnLevel& al = m->attn[l];
@@ -2154,6 +2175,10 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
     const int pt = ph / 2, plft = pw / 2;
     const int ntile = (int)cdivl(HW, 16);
     const float* x = xq;
+    WideTwin xt = xq_twin;
+    // SPL16 operands for the core: every frame it reads has its twin, and every block that produces a frame writes one (mlp_fused_kernel)
+    const bool will_fuse_mlp = m->wide_fuse_mlp && m->wide_fuse_fc2 && m->sb_terms == 2 && C == 256 && ws.tile_count && ws.xaS;
+    const bool spl = m->wide_spl && wide_core2_ok(m, l) && will_fuse_mlp && xq_twin.s && (!prev_frag || prev_twin.s) && al.blocks[0].qkvN >= 0;
     for (int i = blk0; i < blk0 + nblk; ++i) {
         const AttnBlock& ab = al.blocks[i];
         const bool dil = (i % 2) == 1;                       // DTransformer.py:362
@@ -2174,8 +2199,17 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
             }
             a.kvpad = m->P(ab.kvpad_off);
             a.biasW = m->P(ab.biasW_off);
-            a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(ab.qkvHF));
-            a.wqkv_unscale = m->P(ab.qkvHF_unscale);
+            a.wqkvS = reinterpret_cast<const unsigned short*>(m->P(spl ? ab.qkvN : ab.qkvHF));
+            a.wqkv_unscale = m->P(spl ? ab.qkvN_unscale : ab.qkvHF_unscale);
+            if (spl) {
+                a.xS = reinterpret_cast<const unsigned short*>(xt.s);
+                a.xSt = xt.st;
+                a.xpS = prev_frag ? reinterpret_cast<const unsigned short*>(prev_twin.s) : nullptr;
+                a.xpSt = prev_frag ? prev_twin.st : nullptr;
+                a.spl_bs = (long)ntile * 16 * C * 2;          // 16-bit elements: two terms per value
+                a.st_bs = (long)ntile * 16 * 2;
+                a.zeros = m->P(m->zero_off);
+            }
             a.bqkv = m->P(ab.qkv.b_off);
             a.sqkv = m->P(ab.qkv.s_off);
             a.out = ws.ao;
@@ -2257,6 +2291,14 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
             fa.HW = (int)HW; fa.ntile = ntile; fa.B = B;
             fa.mask_w = dil ? W : 0; fa.mask_pt = pt; fa.mask_pl = plft;
             fa.ovf = m->ovf();
+            if (spl) {
+                const WideTwin dt = last ? out_twin : (dst == ws.xa ? WideTwin{ws.xaS, ws.stA} : WideTwin{ws.xbS, ws.stB});
+                fa.out_spl = reinterpret_cast<unsigned short*>(dt.s);
+                fa.out_stats = dt.st;
+                fa.spl_bs = (long)ntile * 16 * C * 2;
+                fa.st_bs = (long)ntile * 16 * 2;
+                xt = dt;
+            }
             fa.stamps = m->tok_debug == 21 ? m->tok_stamps : nullptr;
             ProfScope ps(m, pname("wide_mlp", l), s);
             BDE_TRY(mlp_fused_launch(fa, s));
@@ -2330,7 +2372,14 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         const int ntile = (int)cdivl(HW, 16);
         const long ffs = (long)B * ntile * 16 * C;           // FRAG16 frame stride
         const long q0fs = (long)B * HW * 3 * C;
-        { ProfScope ps(m, pname("to_frag", l), s); BDE_TRY(nchw_to_frag(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s)); }
+        const bool twins = ws.mergedS[l] != nullptr && m->sb_terms == 2;
+        const long sfs = ffs, stfs = (long)B * ntile * 16 * 2;    // SPL16 frame stride (floats of the image) / statistics stride
+        {
+            ProfScope ps(m, pname("to_frag", l), s);
+            if (twins) BDE_TRY(nchw_to_frag_spl(ws.merged[l], ws.mergedT[l], reinterpret_cast<unsigned short*>(ws.mergedS[l]), ws.mstats[l], T * B,
+                                                C, (int)HW, m->ovf(), s));
+            else BDE_TRY(nchw_to_frag(ws.merged[l], ws.mergedT[l], T * B, C, (int)HW, s));
+        }
         if (need_un)
             BDE_TRY(run_tokgemm(m, "wide_kv_all", l, al.kvallW, al.kvall, al.depth * 2 * C, C, ws.mergedT[l], T * B, HW, ws.kvun[l],
                                 nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
@@ -2346,16 +2395,22 @@ static int run_attention_level(bde_model* m, int l, int T, int B, int H, int W, 
         for (int t = 0; t < T; ++t) {
             const float* kvslot[BDE_MAX_FRAMES];
             const float* prev_frag = nullptr;
+            WideTwin qt, pt;
+            if (twins) qt = WideTwin{ws.mergedS[l] + (long)t * sfs, ws.mstats[l] + (long)t * stfs};
             for (int d = 0; d < D; ++d) {
                 const int f = t + c.buffer_index[d];
                 if (d == c.q_idx || f < 0 || f >= T) kvslot[d] = nullptr;
-                else if (f < t && in_core) { kvslot[d] = nullptr; prev_frag = ws.mergedT[l] + (long)f * ffs; }
+                else if (f < t && in_core) {
+                    kvslot[d] = nullptr;
+                    prev_frag = ws.mergedT[l] + (long)f * ffs;
+                    if (twins) pt = WideTwin{ws.mergedS[l] + (long)f * sfs, ws.mstats[l] + (long)f * stfs};
+                }
                 else if (f < t) kvslot[d] = ws.kvref[l] + (long)f * kvfs;      // refined (V5.py:166-169)
                 else kvslot[d] = ws.kvun[l] + (long)f * kvfs;
             }
             float* mtF = ws.mergedT[l] + (long)t * ffs;
             BDE_TRY(run_attention_frame_wide(m, l, mtF, kvslot, mtF, mtF, ws.merged[l] + (long)t * fs, B, H, W, 0, al.depth,
-                                             ws.qkv0[l] + (long)t * q0fs, s, prev_frag, neg_slot));
+                                             ws.qkv0[l] + (long)t * q0fs, s, prev_frag, neg_slot, qt, qt, pt));
             if (need_ref && !in_core && t + 1 < T)
                 BDE_TRY(run_tokgemm(m, "wide_kv", l, al.kvallW, al.kvall, al.depth * 2 * C, C, mtF, B, HW, ws.kvref[l] + (long)t * kvfs,
                                     nullptr, ACT_NONE, nullptr, nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
@@ -3138,7 +3193,13 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
     if (std::string(key) == "wide_kv_sb") { m->wide_kv_sb = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_fuse_mlp") { m->wide_fuse_mlp = (int)value; return BDE_OK; }
     if (std::string(key) == "wide_fuse_fc2") { m->wide_fuse_fc2 = (int)value; return BDE_OK; }
-    if (std::string(key) == "wide_core2") { m->wide_core2 = (int)value; return BDE_OK; }
+    if (std::string(key) == "wide_core2") {
+        if (m->wide_core2 != (int)value)
+            for (auto& w : m->wslots) w.release();           // the SPL16 twins exist only with it
+        m->wide_core2 = (int)value;
+        return BDE_OK;
+    }
+    if (std::string(key) == "wide_spl") { m->wide_spl = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") {
         if (m->conv_sb != (int)value)
             for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it
@@ -3213,6 +3274,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "wide_fuse_mlp") *value = m->wide_fuse_mlp;
     else if (k == "wide_fuse_fc2") *value = m->wide_fuse_fc2;
     else if (k == "wide_core2") *value = m->wide_core2;
+    else if (k == "wide_spl") *value = m->wide_spl;
     else if (k == "sb_terms") *value = m->sb_terms;
     else if (k == "sb_auto") *value = m->sb_auto;
     else if (k == "sb_overflows") *value = m->sb_overflows;       // forwards settled so far whose two-term operands left fp16's range
@@ -3582,22 +3644,31 @@ int bde_op_dframe_attention(bde_model* m, int32_t level, const float* const* buf
         const bool in_core = wide_core2_ok(m, level) && nneg == 1;
         const float* prev_frag = nullptr;
         int prev_slot = -1;
+        WideTwin q_twin, p_twin;
         for (int d = 0; d < D; ++d) {
             kvslot[d] = nullptr;
             if (bufs[d] == nullptr) continue;
             float* fr = w.mergedT[level] + (long)d * ffs;
-            BDE_TRY(nchw_to_frag(bufs[d], fr, B, C, (int)HW, s));
-            if (d == c.q_idx) continue;
+            const bool twins = w.mergedS[level] != nullptr && m->sb_terms == 2;
+            WideTwin tw;
+            if (twins) {
+                tw = WideTwin{w.mergedS[level] + (long)d * ffs, w.mstats[level] + (long)d * B * cdivl(HW, 16) * 16 * 2};
+                BDE_TRY(nchw_to_frag_spl(bufs[d], fr, reinterpret_cast<unsigned short*>(tw.s), tw.st, B, C, (int)HW, m->ovf(), s));
+            } else {
+                BDE_TRY(nchw_to_frag(bufs[d], fr, B, C, (int)HW, s));
+            }
+            if (d == c.q_idx) { q_twin = tw; continue; }
             // as in the forward: the one frame at a negative offset goes to the attention core as it is (wide_core.h)
-            if (in_core && c.buffer_index[d] < 0) { prev_frag = fr; prev_slot = d; continue; }
+            if (in_core && c.buffer_index[d] < 0) { prev_frag = fr; prev_slot = d; p_twin = tw; continue; }
             float* dst = w.kvun[level] + (long)d * kvfs;
             BDE_TRY(run_tokgemm(m, "wide_kv", level, al.kvallW, al.kvall, al.depth * 2 * C, C, fr, B, HW, dst, nullptr, ACT_NONE, nullptr,
                                 nullptr, nullptr, 0, 0, 0, 0, s, al.kvallH, al.kvallH_unscale));
             kvslot[d] = dst;
         }
         float* qf = w.mergedT[level] + (long)c.q_idx * ffs;
+        // (the caller wants the result as NCHW only: the last block's SPL16 twin goes to a scratch pair)
         return run_attention_frame_wide(m, level, qf, kvslot, nullptr, nullptr, out, B, H, W, first_block, nblocks, nullptr, s, prev_frag,
-                                        prev_slot);
+                                        prev_slot, q_twin, q_twin.s ? WideTwin{w.xaS, w.stA} : WideTwin(), p_twin);
     }
     for (int d = 0; d < D; ++d) {
         kvslot[d] = nullptr;

@@ -21,6 +21,69 @@
 
 namespace bde {
 
+// ---- SPL16: a frame of the chain as the B fragments of the 16x16x32 fp16 MFMA, already split into two terms -----------------------------
+//   [B][token tile 16][k-step 32 channels][term][64 lanes][8 x fp16]: lane (token & 15) + 16 g, element j = channel 32 ks + 8 g + j
+//   (16 KB per token tile at 256 channels, the bytes of the fp32 tile), and beside it the LayerNorm statistics of every token,
+//   [B][token][2] = (mean, rstd) over the channels.  Written ONCE by whoever produces a frame (the conversion below for the merged
+//   frames, the last arriver of mlp_fused_kernel for a block's output); the attention core then loads its operand fragments as
+//   they stand -- no split, no running sums, no zero masking in its GEMM loop (6.5 vector instructions per value and token set,
+//   two thirds of that loop's cycles).  The fp32 FRAG16 twin stays: residuals and the final NCHW copy are fp32.
+__host__ __device__ __forceinline__ long spl16_frag(long tile, int nks, int ks, int term) { return ((tile * nks + ks) * 2 + term) * 64; }   // in 16-byte units
+
+// [N][C][HW] planes -> FRAG16 + SPL16 + statistics.  grid (token tiles, N), 256 threads: thread = (token, 16-channel group).
+__global__ __launch_bounds__(256) void nchw_to_frag_spl_kernel(const float* __restrict__ in, float* __restrict__ frag,
+                                                               unsigned short* __restrict__ spl, float* __restrict__ stats, int C, int HW,
+                                                               int ntile, unsigned* ovf) {
+    __shared__ float S1[16][17], S2[16][17];
+    const int tile = blockIdx.x;
+    const long n = blockIdx.y;
+    const int t = threadIdx.x & 15, g = threadIdx.x >> 4;             // token of the tile, channel group (C = 256: 16 groups)
+    const int tok = tile * 16 + t;
+    const int ngc = C >> 4, nks = C >> 5;
+    float v[16];
+    float s1 = 0.f, s2 = 0.f, gm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = tok < HW ? in[(n * C + 16 * g + k) * HW + tok] : 0.f;
+        s1 += v[k];
+        s2 += v[k] * v[k];
+    }
+    // FRAG16: lane (t, g4), element j of group g = channel 16 g + 4 j + g4
+    float* fo = frag + ((n * ntile + tile) * ngc + g) * 256;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(fo + (t + 16 * g4) * 4) = float4{v[g4], v[4 + g4], v[8 + g4], v[12 + g4]};
+    // SPL16: channels 16 g + k = k-step g >> 1, B lane t + 16 ((g & 1) 2 + (k >> 3)), element k & 7
+    uint4* so = reinterpret_cast<uint4*>(spl) + spl16_frag(n * ntile + tile, nks, g >> 1, 0) + t + 16 * ((g & 1) * 2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned tt[4][2];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ws_split_pair_g<2>(v[8 * h + 2 * p], v[8 * h + 2 * p + 1], tt[p], gm);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) so[q * 64 + 16 * h] = uint4{tt[0][q], tt[1][q], tt[2][q], tt[3][q]};
+    }
+    sb_guard_flush(gm, ovf);
+    S1[g][t] = s1;
+    S2[g][t] = s2;
+    __syncthreads();
+    if (g == 0) {
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { u1 += S1[k][t]; u2 += S2[k][t]; }          // fixed order
+        const float mean = u1 / (float)C;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(u2 / (float)C - mean * mean, 0.f) + 1e-5f);
+        *reinterpret_cast<float2*>(stats + ((n * ntile + tile) * 16 + t) * 2) = float2{mean, rstd};
+    }
+}
+static int nchw_to_frag_spl(const float* in, float* frag, unsigned short* spl, float* stats, int N, int C, int HW, unsigned* ovf, hipStream_t s) {
+    if (C != 256) return fail(BDE_ERR_UNSUPPORTED, "SPL16 conversion: C = %d", C);
+    const int ntile = cdiv(HW, 16);
+    hipLaunchKernelGGL(nchw_to_frag_spl_kernel, dim3(ntile, N), dim3(256), 0, s, in, frag, spl, stats, C, HW, ntile, ovf);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
+
 struct WideCoreArgs {
     const float* x;               // FRAG16 [B][ntile][C/16][256]: block input of the query frame
     const float* xp;              // FRAG16: the refined neighbour frame (slot p_slot), nullptr = none handled here
@@ -38,6 +101,11 @@ struct WideCoreArgs {
     int D, C, heads, H, W, Hp, Wp, pt, pl, nWw, dilated, ntile;
     unsigned* ovf;                // range guard of the two-term format (split.h)
     unsigned long long* stamps;   // diagnostics only
+    // SPL = true: the two frames as SPL16 + statistics (above) instead of fp32 FRAG16; wqkvS then in natural k order
+    const unsigned short *xS, *xpS;
+    const float *xSt, *xpSt;      // [B][ntile * 16][2]
+    long spl_bs, st_bs;           // batch strides: 16-bit elements / floats
+    const float* zeros;           // >= 16 bytes of zeros (operand of a padding token)
 };
 #define WC_STAMP(i)                                                                                                  \
     do {                                                                                                             \
@@ -49,7 +117,7 @@ constexpr int WC_WL_BYTES = 3 * 8 * 2 * 1024;
 constexpr int WC_LDS_BYTES = WC_WL_BYTES + (2 * 10 * 16 * 16 + 2 * 48) * 4;      // 68.5 KB: two workgroups per CU
 
 // C = 256 (8 k-steps of 32), head_dim 16, D * 49 <= 160 keys.  grid (windows, heads, B), 256 threads = four query tiles.
-template <bool PREV>
+template <bool PREV, bool SPL>
 __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a) {
     constexpr int HD = 16, NT = 10, NKS = 8;
     extern __shared__ __align__(16) unsigned char wc_lds[];
@@ -79,15 +147,39 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
     // ---- every operand of the launch is requested here ---------------------------------------------------------------------------
     const long xo = ((long)(max(qpix, 0) >> 4) * ngk) * 64 + (max(qpix, 0) & 15) + 16 * g4;
     const wf4* xw = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + xo;
-    // (token fragments: a rolling window of LA k-steps per token set is in flight -- all sixteen k-steps of both sets from the
-    //  start are 128 registers, which with two workgroups per CU is more than a wave has)
+    // (fp32 token fragments: a rolling window of LA k-steps per token set is in flight -- all sixteen k-steps of both sets from
+    //  the start are 128 registers, which with two workgroups per CU is more than a wave has)
     constexpr int LA = 4;
-    const wf4* xpw = PREV ? reinterpret_cast<const wf4*>(a.xp + b * a.x_bs) + xo : xw;
-    wf4 xq[2 * NKS], xpv[PREV ? 2 * NKS : 1];
+    const wf4* xpw = (PREV && !SPL) ? reinterpret_cast<const wf4*>(a.xp + b * a.x_bs) + xo : xw;
+    wf4 xq[SPL ? 1 : 2 * NKS], xpv[(PREV && !SPL) ? 2 * NKS : 1];
+    // SPL16 operands: the lane's 16 bytes of (k-step, term) of its token, 16 per token set, all requested here (a padding token
+    // reads zeros: LayerNorm(0) = beta, i.e. the folded bias alone)
+    sb8 bqS[SPL ? NKS : 1][2], bpS[(SPL && PREV) ? NKS : 1][2];
+    float2 stq = {0.f, 1.f}, stp = {0.f, 1.f};
+    if constexpr (SPL) {
+        const bool live = qpix >= 0;
+        const long so = spl16_frag(max(qpix, 0) >> 4, NKS, 0, 0) + (max(qpix, 0) & 15) + 16 * g4;
+        const int stride = live ? 64 : 0;
+        const sb8* sq = live ? reinterpret_cast<const sb8*>(a.xS + b * a.spl_bs) + so : reinterpret_cast<const sb8*>(a.zeros);
 #pragma unroll
-    for (int kg = 0; kg < 2 * LA; ++kg) {
-        xq[kg] = xw[kg * 64];
-        if constexpr (PREV) xpv[kg] = xpw[kg * 64];
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bqS[ks][t] = sq[(ks * 2 + t) * stride];
+        if (live) stq = *reinterpret_cast<const float2*>(a.xSt + b * a.st_bs + (long)qpix * 2);
+        if constexpr (PREV) {
+            const sb8* sp = live ? reinterpret_cast<const sb8*>(a.xpS + b * a.spl_bs) + so : reinterpret_cast<const sb8*>(a.zeros);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bpS[ks][t] = sp[(ks * 2 + t) * stride];
+            if (live) stp = *reinterpret_cast<const float2*>(a.xpSt + b * a.st_bs + (long)qpix * 2);
+        }
+    } else {
+#pragma unroll
+        for (int kg = 0; kg < 2 * LA; ++kg) {
+            xq[kg] = xw[kg * 64];
+            if constexpr (PREV) xpv[kg] = xpw[kg * 64];
+        }
     }
     {
         // weight fragments: 48 blocks of 1 KiB, twelve per wave; fragment (r, ks, t) of the packed rows: row tile r * ngk + head
@@ -162,11 +254,13 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         __builtin_amdgcn_sched_barrier(0);                             // (keeps the loads and LDS reads of later k-steps out of this one)
-        if (ks + LA < NKS) {
+        if constexpr (!SPL) {
+            if (ks + LA < NKS) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                xq[2 * (ks + LA) + h] = xw[(2 * (ks + LA) + h) * 64];
-                if constexpr (PREV) xpv[2 * (ks + LA) + h] = xpw[(2 * (ks + LA) + h) * 64];
+                for (int h = 0; h < 2; ++h) {
+                    xq[2 * (ks + LA) + h] = xw[(2 * (ks + LA) + h) * 64];
+                    if constexpr (PREV) xpv[2 * (ks + LA) + h] = xpw[(2 * (ks + LA) + h) * 64];
+                }
             }
         }
         if (ks == NKS / 2) {
@@ -180,20 +274,30 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
             fk[t] = *reinterpret_cast<const sb8*>(WL + ((1 * NKS + ks) * 2 + t) * 1024 + lane * 16);
             fv[t] = *reinterpret_cast<const sb8*>(WL + ((2 * NKS + ks) * 2 + t) * 1024 + lane * 16);
         }
-        sb8 bq[2];
-        split_tile(xq[2 * ks], xq[2 * ks + 1], s1, s2, bq);
-        aq = sb_mma16<2>(fq, bq, aq);
-        ak = sb_mma16<2>(fk, bq, ak);
-        av = sb_mma16<2>(fv, bq, av);
-        if constexpr (PREV) {
-            sb8 bp[2];
-            split_tile(xpv[2 * ks], xpv[2 * ks + 1], p1, p2, bp);
-            akp = sb_mma16<2>(fk, bp, akp);
-            avp = sb_mma16<2>(fv, bp, avp);
+        if constexpr (SPL) {
+            aq = sb_mma16<2>(fq, bqS[ks], aq);
+            ak = sb_mma16<2>(fk, bqS[ks], ak);
+            av = sb_mma16<2>(fv, bqS[ks], av);
+            if constexpr (PREV) {
+                akp = sb_mma16<2>(fk, bpS[ks], akp);
+                avp = sb_mma16<2>(fv, bpS[ks], avp);
+            }
+        } else {
+            sb8 bq[2];
+            split_tile(xq[2 * ks], xq[2 * ks + 1], s1, s2, bq);
+            aq = sb_mma16<2>(fq, bq, aq);
+            ak = sb_mma16<2>(fk, bq, ak);
+            av = sb_mma16<2>(fv, bq, av);
+            if constexpr (PREV) {
+                sb8 bp[2];
+                split_tile(xpv[2 * ks], xpv[2 * ks + 1], p1, p2, bp);
+                akp = sb_mma16<2>(fk, bp, akp);
+                avp = sb_mma16<2>(fv, bp, avp);
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    sb_guard_flush(gm, a.ovf);
+    if constexpr (!SPL) sb_guard_flush(gm, a.ovf);       // (SPL16 frames were checked when they were written)
     WC_STAMP(2);
     wf4 qv;
     {
@@ -205,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
             rstd = __builtin_amdgcn_rsqf(fmaxf(u2 / (float)a.C - mean * mean, 0.f) + 1e-5f);
         };
         float mean, rstd;
-        stats(s1, s2, mean, rstd);
+        if constexpr (SPL) { mean = stq.x; rstd = stq.y; }
+        else stats(s1, s2, mean, rstd);
         float kq[4], vq[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -223,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
         }
         if constexpr (PREV) {
             float meanp, rstdp;
-            stats(p1, p2, meanp, rstdp);
+            if constexpr (SPL) { meanp = stp.x; rstdp = stp.y; }
+            else stats(p1, p2, meanp, rstdp);
             if (qi < ATT_TOK) {
                 const int u = a.p_slot * ATT_TOK + qi;
                 float vp[4];
@@ -296,14 +402,19 @@ static int wide_core_launch(const WideCoreArgs& a, int B, hipStream_t s) {
     if (a.C != 256 || a.heads * 16 != a.C || a.D * ATT_TOK > 160)
         return fail(BDE_ERR_UNSUPPORTED, "wide attention core: C = %d, %d heads, D = %d", a.C, a.heads, a.D);
     const int nW = (a.Hp / ATT_WS) * (a.Wp / ATT_WS);
-    static unsigned char raised1[BDE_MAX_DEVICES], raised0[BDE_MAX_DEVICES];
-    if (a.xp) {
-        BDE_HIP(raise_dynamic_lds(raised1, (const void*)wide_core_kernel<true>, WC_LDS_BYTES));
-        hipLaunchKernelGGL(wide_core_kernel<true>, dim3(nW, a.heads, B), dim3(256), WC_LDS_BYTES, s, a);
-    } else {
-        BDE_HIP(raise_dynamic_lds(raised0, (const void*)wide_core_kernel<false>, WC_LDS_BYTES));
-        hipLaunchKernelGGL(wide_core_kernel<false>, dim3(nW, a.heads, B), dim3(256), WC_LDS_BYTES, s, a);
-    }
+    static unsigned char raised[4][BDE_MAX_DEVICES];
+    const bool spl = a.xS != nullptr;
+    const dim3 grid(nW, a.heads, B);
+#define WC_LAUNCH(P, S, i)                                                                                          \
+    do {                                                                                                            \
+        BDE_HIP(raise_dynamic_lds(raised[i], (const void*)wide_core_kernel<P, S>, WC_LDS_BYTES));                    \
+        hipLaunchKernelGGL((wide_core_kernel<P, S>), grid, dim3(256), WC_LDS_BYTES, s, a);                          \
+    } while (0)
+    if (a.xp && spl) WC_LAUNCH(true, true, 0);
+    else if (a.xp) WC_LAUNCH(true, false, 1);
+    else if (spl) WC_LAUNCH(false, true, 2);
+    else WC_LAUNCH(false, false, 3);
+#undef WC_LAUNCH
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "wideblock.h"
+#include "wide_core.h"           // SPL16
 
 namespace bde {
 
@@ -43,6 +44,9 @@ struct MlpFusedArgs {
     int mask_w, mask_pt, mask_pl; // dilated-window coverage mask on the proj output (uncovered pixels: shortcut only)
     unsigned* ovf;                // range guard of the two-term format (split.h)
     unsigned long long* stamps;   // diagnostics only: s_memtime per phase, [workgroup < 64][wave][8]
+    unsigned short* out_spl;      // optional: x2 also as SPL16 (wide_core.h) [B][ntile][8][2][64][8] ...
+    float* out_stats;             // ... with its LayerNorm statistics [B][ntile * 16][2] = (mean, rstd): the next core's operand
+    long spl_bs, st_bs;
 };
 #define WM_STAMP(i)                                                                                                  \
     do {                                                                                                             \
@@ -277,17 +281,47 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[qq][0]), "+v"(pv[qq][1]), "+v"(pv[qq][2]), "+v"(pv[qq][3])::"memory");
+        float s1 = 0.f, s2 = 0.f, gmo = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int rt = 4 * wave + m;
             const long fo = ((long)tile * 16 + rt) * 256 + col * 4 + g4;
             float* op = a.out + b * a.x_bs + fo;
+            float yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float y = ((pv[0][m][r] + pv[1][m][r]) + pv[2][m][r]) + pv[3][m][r];
                 y += ad[m][r];
+                yv[r] = y;
                 op[r * 64] = y;
                 if (a.out_nchw && tok < a.HW) a.out_nchw[b * a.nchw_bs + (long)(rt * 16 + g4 * 4 + r) * a.HW + tok] = y;
+                s1 += y;
+                s2 += y * y;
+            }
+            if (a.out_spl) {
+                // the same four channels as 8 bytes of each term of B lane (col, (rt & 1) 2 + (g4 >> 1)) of k-step rt >> 1
+                unsigned t[2][2];
+                ws_split_pair_g<2>(yv[0], yv[1], t[0], gmo);
+                ws_split_pair_g<2>(yv[2], yv[3], t[1], gmo);
+                unsigned char* d = reinterpret_cast<unsigned char*>(a.out_spl + b * a.spl_bs) +
+                                   (spl16_frag(tile, 8, rt >> 1, 0) + col + 16 * ((rt & 1) * 2 + (g4 >> 1))) * 16 + (g4 & 1) * 8;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(d + q * 1024) = uint2{t[0][q], t[1][q]};
+            }
+        }
+        if (a.out_spl) {
+            // LayerNorm statistics of x2 for its consumers: this wave's 64 channels, then the four waves in a fixed order
+            sb_guard_flush(gmo, a.ovf);
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (lane < 16) { ST[wave][lane][0] = s1; ST[wave][lane][1] = s2; }
+            __syncthreads();                   // (the whole workgroup is the last arriver)
+            if (tid < 16) {
+                const float u = (ST[0][tid][0] + ST[1][tid][0]) + (ST[2][tid][0] + ST[3][tid][0]);
+                const float v = (ST[0][tid][1] + ST[1][tid][1]) + (ST[2][tid][1] + ST[3][tid][1]);
+                const float mean2 = u * (1.f / 256.f);
+                const float rstd2 = __builtin_amdgcn_rsqf(fmaxf(v * (1.f / 256.f) - mean2 * mean2, 0.f) + 1e-5f);
+                *reinterpret_cast<float2*>(a.out_stats + b * a.st_bs + ((long)tile * 16 + tid) * 2) = float2{mean2, rstd2};
             }
         }
     }

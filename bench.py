@@ -30,10 +30,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32 matrix peak (=
 SPLIT_PEAK_TFLOPS = {2: 2500.0 / 3, 3: 2500.0 / 6}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md, HBM3E spec
 ATOMIC_PEAK_GBPS = 1300.0       # MI355X_MICROARCH.md, global float atomics: ~1.3 TB/s of added bytes chip-wide
-PROFILE_TAG = 'r3'              # the committed rocprofv3 artefacts this line cites: profiles/<tag>_*
+PROFILE_TAG = 'r4'              # the committed rocprofv3 artefacts this line cites: profiles/<tag>_*
 PMC_FILE = os.path.join(REPO, 'profiles', PROFILE_TAG + '_pmc.json')
-if not os.path.exists(PMC_FILE):
-    PMC_FILE = os.path.join(REPO, 'profiles', 'r2_pmc.json')
 
 
 def log(msg):
@@ -76,9 +74,10 @@ def host_cores():
 class Work:
     """flops / bytes per launch of each profiled span of one forward (config, T, B, Hp, Wp)."""
 
-    def __init__(self, cfg, T, B, H, W, fuse_x=()):
+    def __init__(self, cfg, T, B, H, W, fuse_x=(), core2=True):
         self.cfg, self.T, self.B, self.H, self.W = cfg, T, B, H, W
         self.fuse_x = set(fuse_x)          # levels whose recurrent step contracts [x | h] itself (no batched gate convolution)
+        self.core2 = core2                 # wide_core.h computes the refined neighbour's K | V inside the attention core
 
     def _lvl(self, l):
         return self.cfg.enc_in(l), self.cfg.enc_out(l), (self.H >> (l + 1)) * (self.W >> (l + 1))
@@ -102,6 +101,16 @@ class Work:
         if m is None:
             return None
         base, idx = m.group(1), int(m.group(2)) if m.group(2) else None
+        if base == 'wide_core':                           # wide_core.h: q|k|v of the query frame's padded tokens, k|v of the refined
+            C = c.enc_out(idx)                            # neighbour's (one negative buffer offset), scores and p.v over D*49 keys
+            h, w = self.H >> (idx + 1), self.W >> (idx + 1)
+            npad = (-(-h // 7) * 7) * (-(-w // 7) * 7)
+            nneg = sum(1 for d, o in enumerate(c.buffer_index) if d != c.q_idx and o < 0)
+            prev = 2.0 * npad * 2 * C * C if (self.core2 and nneg == 1) else 0.0
+            return B * (2.0 * npad * 3 * C * C + prev + 4.0 * npad * c.frame_num * 49 * C), 'mfma'
+        if base == 'wide_mlp':                            # wide_mlp.h: proj + fc1 + fc2 on the unpadded map
+            C = c.enc_out(idx)
+            return B * (self.H >> (idx + 1)) * (self.W >> (idx + 1)) * 2.0 * 9 * C * C, 'mfma'
         if base.startswith('wide_'):                      # the fragment-layout chain runs the same GEMMs as the split path
             base = 'chain_' + base[5:]
         if base == 'head':
@@ -146,6 +155,38 @@ class Work:
             return B * hw * 2.0 * (C * C + 8 * C * C + 3 * C * C), 'mfma'
         return None
 
+    def split_share(self, name, info):
+        """Fraction of a span's flops that the library issues on the 16-bit matrix cores from split operands (csrc/split.h)
+        -- the rest runs as fp32 MFMAs or fp32 vector work, both 157.3 TFLOP/s dense.  `info` = the library's own report of
+        what the latest forward launched (bde_get_info)."""
+        c = self.cfg
+        m = re.fullmatch(r'([a-z_]+?)(\d*)', name)
+        base, idx = m.group(1), int(m.group(2)) if m.group(2) else None
+        if base in ('head', 'enc_conv', 'gates_x', 'dec_conv', 'lstm'):
+            key = {'head': 'sb_head', 'enc_conv': f'sb_enc{idx}', 'gates_x': f'sb_gx{idx}', 'dec_conv': f'sb_dec{idx}', 'lstm': f'sb_lstm{idx}'}[base]
+            return 1.0 if info(key) == 1 else 0.0
+        if base == 'winblock':
+            if info('winblock_sb') != 1:
+                return 0.0
+            C, D = c.enc_out(idx), c.frame_num
+            h, w = self.H >> (idx + 1), self.W >> (idx + 1)
+            npad = (-(-h // 7) * 7) * (-(-w // 7) * 7)
+            attn = self.B * 4.0 * npad * D * 49 * C                     # scores (fp32 MFMA) + p.v (vector ALU)
+            return 1.0 - attn / self.attn_block_flops(idx)
+        if base == 'wide_core':                                         # q|k|v (+ the refined neighbour's k|v) split, scores / p.v fp32 MFMA
+            if not (info('wide_kv_sb') == 1 and info('sb_terms') == 2):
+                return 0.0
+            fl, _ = self.flops(name)
+            C = c.enc_out(idx)
+            h, w = self.H >> (idx + 1), self.W >> (idx + 1)
+            npad = (-(-h // 7) * 7) * (-(-w // 7) * 7)
+            return 1.0 - self.B * 4.0 * npad * c.frame_num * 49 * C / fl
+        if base in ('wide_mlp', 'wide_projfc'):
+            return 1.0 if (info('wide_fuse_mlp') == 1 and info('sb_terms') == 2) else 0.0
+        if base in ('wide_kv', 'wide_kv_all'):
+            return 1.0 if (info('wide_kv_sb') == 1 and info('sb_terms') == 2) else 0.0
+        return 0.0
+
     def first_step_flops(self, l):
         """The first step of a sweep starts from h = 0 and skips the h-part of the contraction."""
         cin, cout, hw = self._lvl(l)
@@ -177,9 +218,10 @@ KERNEL_OF_SPAN = [
     (r'dec_conv(\d)', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'decoder {0}: 5x5 conv on the bilinear x2 of (x + skip), batched over T (csrc/conv_sb.h / conv_vec.h)'),
     (r'head', r'conv_sb_kernel<5, 1|conv_vec_kernel<5, 1', 'head 5x5 conv, batched over T (csrc/conv_sb.h / conv_vec.h)'),
     (r'chain_(\w+?)(\d)', r'pw_gemm_kernel|attn_mfma16_kernel|attn_core_kernel|token_fused_kernel', 'split attention path of level {1}: {0}'),
+    (r'wide_mlp(\d)', r'mlp_fused_kernel', 'token half of a level-{0} attention block in one launch: x1 = x + proj(.), GELU(fc1(LN(x1))), x2 = x1 + fc2(.), two-term split operands, fc2 K-split over four workgroups summed in fixed order by the last to arrive (csrc/wide_mlp.h)'),
     (r'wide_projfc(\d)', r'projfc1_sb_kernel', 'x1 = x + proj(.) and GELU(fc1(LN(x1))) of a level-{0} attention block in one launch, two-term split operands (csrc/wideblock.h)'),
     (r'wide_kv(_all)?(\d)', r'tokgemm_sb_kernel|tokgemm_kernel', 'K|V GEMM of the level-{1} attention chain (csrc/wideblock.h: two-term split operands)'),
-    (r'wide_core(\d)', r'attn_tok16_kernel', 'window-attention core of level {0}, one workgroup per (window, head) (csrc/wideblock.h)'),
+    (r'wide_core(\d)', r'wide_core_kernel|attn_tok16_kernel', 'window half of a level-{0} attention block, one workgroup per (window, head): q|k|v of the query frame and k|v of the refined neighbour on two-term operands, scores / softmax / p.v fp32 (csrc/wide_core.h)'),
     (r'wide_(\w+?)(\d)', r'tokgemm_kernel', 'token GEMM of the level-{1} attention chain: {0} (csrc/wideblock.h)'),
 ]
 
@@ -192,14 +234,18 @@ def describe_span(name):
     return None, name
 
 
-def pmc_traffic(span, avg_us):
+def pmc_traffic(span, avg_us, workload):
     """HBM bytes per launch of the kernel behind `span` from the committed rocprofv3 --pmc passes of THIS round
-    (tools/gpu_pmc_all.sh -> profiles/r2_pmc.json), with provenance; None when the file has no such kernel."""
+    (tools/gpu.sh <tag> pmc -> profiles/<tag>_pmc.json), corrected as MI355X_MICROARCH.md (HBM) prescribes: on gfx950
+    FETCH_SIZE tallies a wide coalesced read at half its bytes -- doubled -- and WRITE_SIZE is exact.  The counters were
+    collected on ONE workload (recorded in the file): for any other (T, B, H, W) the answer is None."""
     try:
         with open(PMC_FILE) as f:
             pmc = json.load(f)
     except Exception:
         return None, None
+    if pmc.get('workload') != workload:
+        return None, {'file': os.path.relpath(PMC_FILE, REPO), 'why': f'counters were collected on {pmc.get("workload")}, this run is {workload}'}
     spans = pmc.get('spans', {})
     ent = spans.get(span)
     if ent is None:                                  # families sharing a kernel template ("gates_x*"): nearest duration
@@ -209,12 +255,13 @@ def pmc_traffic(span, avg_us):
                 ent = min(cands, key=lambda e: abs((e.get('avg_us') or 0) - avg_us))
     if isinstance(ent, list):
         ent = min(ent, key=lambda e: abs((e.get('avg_us') or 0) - avg_us))
-    if not ent:
+    if not ent or ent.get('fetch_bytes') is None or ent.get('write_bytes') is None:
         return None, None
     prov = {'file': os.path.relpath(PMC_FILE, REPO), 'kernel': ent.get('kernel'), 'dispatches': ent.get('dispatches'),
             'fetch_bytes_raw': ent.get('fetch_bytes'), 'write_bytes': ent.get('write_bytes'),
-            'avg_us_in_pmc_pass': ent.get('avg_us'), 'tag': pmc.get('tag'), 'note': pmc.get('note')}
-    return ent.get('hbm_bytes_per_launch'), prov
+            'correction': 'traffic = 2 x FETCH_SIZE (gfx950 tallies 16 B/lane coalesced reads at half) + WRITE_SIZE',
+            'avg_us_in_pmc_pass': ent.get('avg_us'), 'tag': pmc.get('tag'), 'workload': pmc.get('workload'), 'note': pmc.get('note')}
+    return 2.0 * ent['fetch_bytes'] + ent['write_bytes'], prov
 
 
 def voxel_report(device, T, sensor_hw, n_events, vox_dt):
@@ -441,6 +488,38 @@ def main():
         torch.cuda.synchronize(device)
         barrier()
         single_elapsed = time.perf_counter() - t1
+        # ---- strict fp32: the same K steps with every split-operand kernel off (fp32 MFMA / fp32 vector arithmetic throughout:
+        # what the path does with exact fp32 products), same number of sequences in flight, frames checked against the same fixture
+        STRICT = dict(conv_sb=0, lstm_sbk=0, winblock_sb=0, wide_kv_sb=0, wide_fuse_mlp=0)
+        for k, v in STRICT.items():
+            model.set_tuning(k, v)
+        model.set_tuning('pipeline', args.pipeline)
+        for i in range(2 * args.pipeline):
+            model(inputs)
+        model.wait()
+        torch.cuda.synchronize(device)
+        barrier()
+        t2 = time.perf_counter()
+        strict_last = None
+        for _ in range(args.steps):
+            strict_last = model(inputs)
+        model.wait()
+        torch.cuda.synchronize(device)
+        barrier()
+        strict_elapsed = time.perf_counter() - t2
+        strict_ok, strict_err = None, None
+        if can_verify:
+            ok, strict_err = workload.verify_against_fixture(torch.stack(strict_last), fixture[0])
+            strict_ok = bool(min_over_ranks(1.0 if ok else 0.0, device) > 0.5)
+            strict_err = max_over_ranks(strict_err, device)
+        strict_sb = [model.get_info(k) for k in ('sb_head', 'sb_enc0', 'sb_dec0', 'sb_lstm0', 'sb_lstm2')]
+        for k in STRICT:
+            model.set_tuning(k, 1)
+        for kv in tuning.split(','):                              # (BDE_TUNING may have set one of them)
+            if '=' in kv:
+                k, v = kv.split('=')
+                model.set_tuning(k, int(v))
+        log(f'strict fp32: {args.steps * T * B / strict_elapsed:.1f} frames/s, verified={strict_ok}')
         # ---- per-kernel spans: HIP events around every launch, on the launch stream.  Events recorded inside a
         # replayed hipGraph cannot be read back, so the spans come from a few extra EAGER, un-pipelined steps
         # run right after the timed region (same inputs, same kernels).
@@ -453,6 +532,7 @@ def main():
         torch.cuda.synchronize(device)
     elapsed = max_over_ranks(elapsed, device)
     single_elapsed = max_over_ranks(single_elapsed, device)
+    strict_elapsed = max_over_ranks(strict_elapsed, device)
     log(f'timed region done: {elapsed:.3f} s for {args.steps} steps')
 
     if rank == 0:
@@ -468,7 +548,18 @@ def main():
         fuse_x = [l for l in range(cfg.num_encoders)
                   if model.get_info('lstm_fuse_x') == 1 and model.get_info(f'sb_lstm{l}') == 1 and model.get_info(f'sb_gx{l}') == 0
                   and spans.get(f'gates_x{l}', (0, 0))[1] == 0]
-        work = Work(cfg, T, B, H, W, fuse_x)
+        work = Work(cfg, T, B, H, W, fuse_x, core2=model.get_info('wide_core2') == 1)
+        info = model.get_info
+        split_peak = SPLIT_PEAK_TFLOPS[terms]
+
+        def blended_peak(pairs):
+            """Roof of a span (or a stage) that issues part of its flops on the 16-bit matrix cores from split operands and the rest
+            as fp32 MFMAs / fp32 vector work: total flops / (split flops / split peak + fp32 flops / fp32 peak)."""
+            fs = sum(f * sh for f, sh in pairs)
+            ff = sum(f * (1.0 - sh) for f, sh in pairs)
+            t = fs / split_peak + ff / FP32_MFMA_PEAK_TFLOPS
+            return (fs + ff) / t if t > 0 else FP32_MFMA_PEAK_TFLOPS
+
         kernels = {}
         for nm, (ms, cnt) in spans.items():
             fb = work.flops(nm)
@@ -480,45 +571,44 @@ def main():
                 l = int(nm[4:])
                 total_fl = (cnt - n_eager) * fl + n_eager * work.first_step_flops(l)
             kernels[nm] = dict(ms_per_forward=ms / n_eager, launches_per_forward=cnt / n_eager, avg_us=ms / cnt * 1e3,
-                               flops_per_launch=fl, achieved=total_fl / (ms * 1e-3) / 1e12, bound=bound)
+                               flops_per_launch=fl, achieved=total_fl / (ms * 1e-3) / 1e12, bound=bound, _total=total_fl)
         fwd_ms = spans.get('forward', (0.0, 0))[0] / max(n_eager, 1)
-        # spans whose contraction ran as split bf16 (csrc/conv_sb.h; the library says which: bde_get_info "sb_gx<l>" / "sb_enc<l>" /
-        # "sb_dec<j>"; spans include the SB16 conversion of the input)
-        sb_key = {'gates_x': 'sb_gx', 'enc_conv': 'sb_enc', 'dec_conv': 'sb_dec', 'lstm': 'sb_lstm'}
         for nm, k in kernels.items():
             k['share'] = k['ms_per_forward'] / fwd_ms if fwd_ms > 0 else None
-            mm = re.fullmatch(r'(gates_x|enc_conv|dec_conv|lstm)(\d)', nm)
-            split = (bool(mm) and model.get_info(sb_key[mm.group(1)] + mm.group(2)) == 1) or \
-                    (nm == 'head' and model.get_info('sb_head') == 1)                        # what the library launched
-            # level-2 chain: the K|V GEMMs and proj + fc1 run on two-term operands (csrc/wideblock.h) unless switched off; the
-            # attention core (q|k|v two-term, scores / p.v fp32) and fc2 are priced against the fp32 peak
-            if terms == 2 and ((re.fullmatch(r'wide_projfc\d', nm) and model.get_info('wide_fuse_mlp') == 1) or
-                               (re.fullmatch(r'wide_(kv|kv_all)\d', nm) and model.get_info('wide_kv_sb') == 1)):
-                split = True
-            k['peak'] = SPLIT_PEAK_TFLOPS[terms] if split else FP32_MFMA_PEAK_TFLOPS
-            if split:
-                k['bound'] = ('mfma (fp16 matrix cores, two-term split operands: 3 MFMAs per fp32 block)' if terms == 2 else
-                              'mfma (bf16 matrix cores, three-term split operands: 6 MFMAs per fp32 block)')
+            sh = work.split_share(nm, info)                 # what the library launched (bde_get_info), per arithmetic class
+            k['split_share'] = round(sh, 4)
+            k['peak'] = blended_peak([(1.0, sh)])
+            if sh > 0:
+                k['bound'] = (f'mfma: {sh:.0%} of the flops on the {"fp16" if terms == 2 else "bf16"} matrix cores from '
+                              f'{"two" if terms == 2 else "three"}-term split operands ({3 if terms == 2 else 6} MFMAs per fp32 block, '
+                              f'{split_peak:.1f} TFLOP/s), the rest fp32 (157.3): peak = flops / (split flops / {split_peak:.1f} + fp32 flops / 157.3)')
             k['frac'] = k['achieved'] / k['peak']
         dom = max(kernels, key=lambda n: kernels[n]['ms_per_forward'])
         dk = kernels[dom]
         kre, desc = describe_span(dom)
-        traffic, prov = pmc_traffic(dom, dk['avg_us'])
+        wl_key = {'T': T, 'B': B, 'H': H, 'W': W}
+        traffic, prov = pmc_traffic(dom, dk['avg_us'], wl_key)
         # stages (same eager steps): encoder = enc convs + gate convs + recurrent steps (the north star's yardstick)
         sf = work.stage_flops()
+        stage_pat = {'encoder_stage': r'(enc_conv|gates_x|lstm)\d', 'head': r'head', 'decoder': r'dec_conv\d'}
         stage_ms = {'encoder_stage': sum(ms for nm, (ms, _) in spans.items() if re.fullmatch(r'(enc_conv|gates_x|lstm)\d', nm)),
                     'head': spans.get('head', (0, 0))[0],
                     'decoder': sum(ms for nm, (ms, _) in spans.items() if re.fullmatch(r'dec_(conv|up)\d', nm)) + spans.get('pred', (0, 0))[0]}
         for l in range(cfg.num_encoders):
             if cfg.depths[l] > 0:
                 stage_ms[f'attention_l{l}'] = spans.get(f'attn{l}', (0, 0))[0]
+                stage_pat[f'attention_l{l}'] = rf'(winblock|wide_\w+?|chain_\w+?){l}'
         stages = {}
         for nm, fl in sf.items():
             ms = stage_ms.get(nm, 0.0)
             if ms > 0:
                 tf = fl * n_eager / (ms * 1e-3) / 1e12
-                stages[nm] = dict(flops_per_forward=fl, ms_per_forward=ms / n_eager, achieved=tf, unit='TFLOP/s',
-                                  frac=tf / FP32_MFMA_PEAK_TFLOPS)
+                # roof of the stage: blended over the spans that make it up, by what each of them issued
+                pairs = [(k['_total'], k['split_share']) for sp, k in kernels.items() if re.fullmatch(stage_pat[nm], sp)]
+                pk = blended_peak(pairs) if pairs else FP32_MFMA_PEAK_TFLOPS
+                stages[nm] = dict(flops_per_forward=fl, ms_per_forward=ms / n_eager, achieved=tf, unit='TFLOP/s', peak=pk, frac=tf / pk)
+        for k in kernels.values():
+            k.pop('_total', None)
         frames = args.steps * T * B * world
         out = {
             'metric': 'reconstructed frames/sec at 5x240x180 voxels, seq_len=16',
@@ -529,10 +619,17 @@ def main():
                       '3 MFMAs per fp32 block, f32 accumulate)' if terms == 2 else
                       'f32 (operands split into three bf16 terms on the matrix cores where conv_sb / lstm_sb / winblock_sb apply: '
                       '6 MFMAs per fp32 block, f32 accumulate)'), 'data': 'synthetic',
-            'single_stream': {'value': args.steps * T * B * world / single_elapsed, 'unit': 'frames/s',
-                              'ms_per_step': 1e3 * single_elapsed / args.steps, 'graph_replay': bool(single_graph),
-                              'what': f'the same {args.steps} steps with ONE sequence in flight per GPU (pipeline 1): per-sequence '
-                                      'latency; `value` overlaps `config.pipeline` independent sequences'},
+            'single_stream_fps': args.steps * T * B * world / single_elapsed,
+            'single_stream_ms': 1e3 * single_elapsed / args.steps,
+            'single_stream_note': (f'the same {args.steps} steps with ONE sequence in flight per GPU (pipeline 1, graph replay '
+                                   f'{bool(single_graph)}): per-sequence latency, each call waits for its frames (range guard of the '
+                                   'two-term format); `value` overlaps `config.pipeline` independent sequences'),
+            'strict_fp32': {'value': args.steps * T * B * world / strict_elapsed, 'unit': 'frames/s',
+                            'ms_per_step': 1e3 * strict_elapsed / args.steps, 'verified': strict_ok, 'max_abs_err': strict_err,
+                            'pipeline': args.pipeline,
+                            'what': 'the same steps with every split-operand kernel switched off (' +
+                                    ', '.join(f'{k}=0' for k in STRICT) + '): fp32 MFMAs and fp32 vector arithmetic throughout',
+                            'split_kernels_launched': strict_sb},
             'profile_set': f'profiles/{PROFILE_TAG}_* (rocprofv3 --kernel-trace --stats of this command and of --pipeline 1; PMC passes)',
             'verified': verified,
             'verification': ({'against': f'{os.path.relpath(fixture[0], REPO)} (the reference\'s frames for these events)',
@@ -556,10 +653,11 @@ def main():
                          'flops_per_launch': dk['flops_per_launch'], 'share_of_forward': dk['share'],
                          'chosen': 'the kernel with the largest total time among the HIP-event spans of this run',
                          'stages': stages,
-                         'stages_note': 'fp32-equivalent flops / time against the fp32 matrix peak (157.3); the spans whose '
-                                        f'kernels[*].peak is {SPLIT_PEAK_TFLOPS[terms]:.1f} ran on split operands on the 16-bit matrix '
-                                        f'cores (dense peak 2500 / {3 if terms == 2 else 6} MFMAs per fp32 block, csrc/split.h); '
-                                        f'recurrent steps of levels {fuse_x} contract [x | h] (no gates_x launch)',
+                         'stages_note': 'fp32-equivalent flops / time; every peak is the blended roof of what the span or stage issued: '
+                                        f'split-operand flops against {SPLIT_PEAK_TFLOPS[terms]:.1f} TFLOP/s (dense 16-bit matrix peak 2500 / '
+                                        f'{3 if terms == 2 else 6} MFMAs per fp32 block, csrc/split.h), fp32 MFMA and vector flops against '
+                                        f'157.3; kernels[*].split_share says how much of a span is which; recurrent steps of levels '
+                                        f'{fuse_x} contract [x | h] (no gates_x launch)',
                          'kernels': {nm: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in kk.items()}
                                      for nm, kk in sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_forward'])},
                          'eager_forward_ms': fwd_ms,

@@ -19,7 +19,9 @@ import sys
 SPAN_KERNELS = [
     ('winblock0', r'winblock_sb_kernel|winblock_kernel'),
     ('wide_*(tokgemm)', r'tokgemm_kernel'),
-    ('wide_core2', r'attn_tok16_kernel'),
+    ('wide_core2', r'wide_core_kernel|attn_tok16_kernel'),
+    ('wide_mlp2', r'mlp_fused_kernel'),
+    ('wide_kv_all2', r'tokgemm_sb_kernel'),
     ('lstm0', r'lstm_sb_step_kernel<4, 1, 2|lstm16_step_kernel<1, 128, 2'),
     ('lstm1', r'lstm_sb_step_kernel<2, 2, 2|lstm16_step_kernel<1, 64, 1'),
     ('lstm2', r'lstm_sb_step_kernel<1, 4, 3|lstm16_step_kernel<2, 32, 1'),
@@ -84,7 +86,9 @@ def main():
             spans[span] = sorted(cands, key=lambda e: -(e['avg_us'] or 0) * e['dispatches'])
         else:
             spans[span] = max(cands, key=lambda e: (e['avg_us'] or 0) * e['dispatches'])
-    out = dict(tag=tag,
+    # the workload the passes ran on (bench.py's default command: config 2); bench.py quotes the bytes for this workload only
+    wl = json.loads(os.environ.get('BDE_PMC_WORKLOAD', '{"T": 16, "B": 1, "H": 184, "W": 240}'))
+    out = dict(tag=tag, workload=wl,
                note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace only) over '
                     '`bench.py --pipeline 1 --steps 2 --warmup 1 --no-cpu-baseline`; per-launch averages; FETCH_SIZE raw '
                     '(gfx950 tallies a 16 B/lane coalesced read at half its bytes, MI355X_MICROARCH.md HBM section)',

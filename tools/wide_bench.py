@@ -20,7 +20,7 @@ m.set_tuning('wide', 0)
 y_old = ops.dframe_attention(m, 2, bufs)
 m.set_tuning('wide', 1)
 print('max |wide - split path| over 6 blocks:', float((y - y_old).abs().max()))
-SETTINGS = [dict(wide_fuse_fc2=0, wide_core2=0), dict(wide_fuse_fc2=1, wide_core2=0), dict(wide_fuse_fc2=1, wide_core2=1)]
+SETTINGS = [dict(wide_fuse_fc2=0, wide_core2=0, wide_spl=0), dict(wide_fuse_fc2=1, wide_core2=1, wide_spl=0), dict(wide_fuse_fc2=1, wide_core2=1, wide_spl=1)]
 for st in SETTINGS:
     for k, v in st.items():
         m.set_tuning(k, v)
