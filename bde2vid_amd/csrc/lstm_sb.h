@@ -34,6 +34,12 @@
 
 namespace bde {
 
+// 16-byte slots of a pixel in the step kernel's halo tiles (see the kernel): no pad slot in the two-term format
+#ifndef LSB_SWZ
+#define LSB_SWZ 1
+#endif
+__host__ __device__ constexpr int lsb_slots(int terms) { return (terms == 2 && LSB_SWZ) ? 4 : sb_lds_slots(terms); }
+
 struct LstmSbArgs {
     const unsigned char* hin;       // SB16 image of h_prev, group g, frame n: hin + g * hin_gs + n * hin_ns (bytes)
     long hin_gs, hin_ns;
@@ -61,6 +67,18 @@ struct LstmSbArgs {
     unsigned long long* stamps;     // diagnostics only: s_memtime per phase, [block < 64][wave < 4][8]
     int stamp_mode;                 // 1: instead, s_memrealtime start / end of every workgroup < 1000 ([wg][2])
 };
+#ifndef LSB_PF1
+#define LSB_PF1 5
+#endif
+#ifndef LSB_PFK
+#define LSB_PFK 8
+#endif
+#ifndef LSB_COUNTED_WAIT
+#define LSB_COUNTED_WAIT 0
+#endif
+#ifndef LSB_STAGGER
+#define LSB_STAGGER 0
+#endif
 #define LSB_STAMP(i)                                                                              \
     do {                                                                                          \
         if (a.stamps && !a.stamp_mode && lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)       \
@@ -72,7 +90,12 @@ struct LstmSbArgs {
 template <int RTW, int KW, int NT, int MAXI, bool DB, int TERMS>
 __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a) {
     static_assert(RTW * KW == 4, "four waves per workgroup");
-    constexpr int SB_PIX_BYTES = sb_pix_bytes(TERMS), SB_LDS_PITCH = sb_lds_pitch(TERMS), SLOTS = sb_lds_slots(TERMS);
+    // Halo tiles in LDS.  Three terms: a pixel's 16-byte slots (two per term) + one pad slot, the pitch conv_sb.h uses.  Two terms:
+    // NO pad slot -- 64 bytes per pixel, 20 % less LDS, which is what lets the tiles of level 1 be double-buffered with three
+    // workgroups on a CU -- and the four slots of pixel p stored at slot ^ ((p >> 2) & 3) instead: sixteen lanes reading the same
+    // logical slot of sixteen consecutive pixels then still hit sixteen different 16-byte bank groups (4 (p & 3) + (slot ^ (p >> 2 & 3))).
+    constexpr bool SWZ = TERMS == 2 && LSB_SWZ;
+    constexpr int SB_PIX_BYTES = sb_pix_bytes(TERMS), SLOTS = lsb_slots(TERMS), SB_LDS_PITCH = 16 * SLOTS;
     constexpr int QW = 4 / KW;                          // register groups (= hidden channels x 2) a wave finishes per tile
     extern __shared__ __align__(16) unsigned char lsb[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,6 +129,14 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     const int y0 = ty * a.TR, x0 = tx * a.TC;
     const int tc = min(a.TC, a.W - x0), tr = min(a.TR, a.H - y0);   // live extent of this tile
     const int IW = a.TC + 2, IR = a.TR + 2;
+    if (LSB_STAGGER) {
+        // The workgroups of a launch start together and meet the same barriers at the same cadence, so the two or three that share
+        // a CU wait for their halo tiles at the same time and nobody computes meanwhile.  The dispatch rounds (one workgroup per
+        // CU each) start a third of a stage apart instead.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned round = (lin >> 8) % 3u;
+        for (unsigned i = 0; i < round * LSB_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);     // 127 x 64 cycles each
+    }
     LSB_STAMP(0);
     const unsigned long long real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostics: 100 MHz reference clock)
 
@@ -119,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         const bool ok = py < tr && px < tc;
         pix[t] = ok ? (y0 + py) * a.W + x0 + px : -1;
         const int cy = min(py, a.TR - 1), cx = min(px, a.TC - 1);   // (dead lanes read inside the tile)
-        boff[t] = (cy * IW + cx) * SB_LDS_PITCH + hl * 16;
+        boff[t] = SWZ ? cy * IW + cx : (cy * IW + cx) * SB_LDS_PITCH + hl * 16;      // (swizzled: the pixel index, see the tap loop)
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -168,8 +199,9 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
             const int px = i / SLOTS, qs = i - px * SLOTS;
             const int r = (int)(((float)px + 0.5f) * inv_iw), c = px - r * IW;      // (exact for px < 2^20; an integer division by a
             const int iy = y0 - 1 + r, ix = x0 - 1 + c;                           //  run-time divisor is ~40 instructions, MAXI times)
-            const bool ok = part < KW && i < nslots && qs < SLOTS - 1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            goff[it] = ok ? (unsigned)((iy * a.W + ix) * SB_PIX_BYTES + qs * 16) : 0u;
+            const int piece = SWZ ? (qs ^ ((px >> 2) & 3)) : qs;                  // the 16-byte piece of the pixel that lives in this slot
+            const bool ok = part < KW && i < nslots && (SWZ || qs < SLOTS - 1) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            goff[it] = ok ? (unsigned)((iy * a.W + ix) * SB_PIX_BYTES + piece * 16) : 0u;
             if (ok) vmask |= 1u << it;
             pmask |= (unsigned long long)(part & 3) << (2 * it);
         }
@@ -191,7 +223,13 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
             }
         };
         // weight fragments of this wave: row tile rt, chunks kp * stages .. + stages - 1 (consecutive in memory)
-        constexpr int TAPS = 9, RING = 3, PF = 2;
+        // Weight fragments run PF taps ahead of the MFMAs that use them.  The ring has one position per tap of a stage (the position
+        // of a tap is a compile-time constant), of which PF + 1 are live at a time.  Two taps ahead (round 3) left the matrix pipe
+        // waiting for L2: in-kernel, level 0, the stage loop went 54.9 k -> 40.6 k cycles with the whole stage ahead -- 91 % matrix
+        // duty -- but 72 registers of fragments cost the third workgroup per CU (692 workgroups: a second dispatch round, 61 us
+        // instead of 54).  PF = 5 keeps three workgroups per CU where a wave takes all of K (KW = 1), PF = 8 elsewhere.
+        constexpr int TAPS = 9, RING = 9, PF = KW == 1 ? LSB_PF1 : LSB_PFK;
+        static_assert(PF >= 1 && PF < RING, "");
         const int S = stages * TAPS;
         const sb8* wfr = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) +
                          (((long)min(rt, nrt - 1) * KC + (long)kp * stages) * TAPS * TERMS) * 64 + lane;
@@ -208,11 +246,23 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                 stage(s);
             }
             if (s == stages - 1) epi_load();             // the tail's operands travel during the last stage
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                             // stage s has landed for every wave (and, DB: stage s - 1's tiles are free)
+            if (LSB_COUNTED_WAIT && DB && s > 0 && s < stages - 1) {
+                // stage s was requested before the PF taps of weight fragments that are still in flight: the counted wait covers
+                // it and leaves them alone; the barrier as asm (memory clobber: LDS reads may not cross it)
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PF * TERMS) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                         // stage s has landed for every wave (and, DB: stage s - 1's tiles are free)
+            }
             if (DB && s + 1 < stages) stage(s + 1);
             const unsigned char* tile = lsb + (DB ? (s & 1) * set_bytes : 0) + kp * tile_bytes;
             if (s == 0) LSB_STAMP(2);
+            if constexpr (SWZ) {
+                // (the swizzled fragment addresses of the nine taps are a few vector instructions each; hoisted out of the stage
+                //  loop -- they do not depend on the stage -- they are 18 NT registers and the third workgroup of a CU)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(boff[t]));
+            }
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int cur = tap % RING, nxt = (tap + PF) % RING;
@@ -224,10 +274,18 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                 const int ky = tap / 3, kx = tap - ky * 3;
                 sb8 bfr[NT][TERMS];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (SWZ) {
+                        const int p = boff[t] + ky * IW + kx;                        // pixel of the tile this lane reads for this tap
+                        const int o0 = p * 64 + ((hl ^ ((p >> 2) & 3)) << 4);        // term 0 = pieces hl, term 1 = pieces 2 + hl: slot ^ 2
+                        bfr[t][0] = *reinterpret_cast<const sb8*>(tile + o0);
+                        bfr[t][1] = *reinterpret_cast<const sb8*>(tile + (o0 ^ 32));
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < TERMS; ++k)
-                        bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
+                        for (int k = 0; k < TERMS; ++k)
+                            bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = sb_mma32<TERMS>(af[cur], bfr[t], acc[t]);
             }
@@ -334,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 struct LstmSbShape { int rtw, kw, nt, TR, TC, tiles_x, tiles_y, maxi; size_t lds; bool ok, db; };
 
 // How a level's step is cut (see the header): KW parts of K per workgroup by the number of 16-channel chunks, NT by the map width.
-static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw, int terms) {
+// GB = directions x batch of the launch (sizes the grid: how many workgroups a CU has to hold at once)
+static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw, int terms, int GB = 2) {
     LstmSbShape s{};
     s.ok = false;
     const int C16 = Ch / 16;
@@ -348,18 +407,21 @@ static inline LstmSbShape lstm_sb_shape_kw(int Ch, int H, int W, int kw, int ter
     s.tiles_x = cdiv(W, s.TC);
     s.tiles_y = cdiv(H, s.TR);
     const long halo = (long)(s.TR + 2) * (s.TC + 2);
-    const long nblk = (halo * sb_lds_slots(terms) + 63) / 64;
+    const long nblk = (halo * lsb_slots(terms) + 63) / 64;
     const long blocks = nblk * s.kw;
     s.maxi = (int)((blocks + 3) / 4);
     const size_t stage_b = (size_t)blocks * 1024;
     const size_t red_b = s.kw > 1 ? (size_t)4 * s.nt * 16 * 64 * 4 : 0;
     const size_t hst_b = (size_t)s.rtw * s.nt * 32 * terms * 16;
-    s.db = 2 * stage_b * 3 <= 150 * 1024;                 // double-buffered halo while three workgroups still fit a CU
+    // double-buffered halo tiles while every workgroup of the launch is still resident: three per CU, or two where the grid has
+    // at most 512 workgroups (level 2 of config A: 2 x 80 KB = the whole LDS of a CU, nothing static in the kernel)
+    const long wgs = (long)s.tiles_x * s.tiles_y * cdiv(Ch / 8, s.rtw) * GB;
+    s.db = wgs <= 512 ? 2 * stage_b * 2 <= 160 * 1024 : 2 * stage_b * 3 <= 150 * 1024;
     s.lds = std::max((s.db ? 2 : 1) * stage_b, std::max(red_b, hst_b));
     s.ok = s.maxi <= 24 && s.lds <= 80 * 1024;            // (two workgroups per CU at least)
     return s;
 }
-static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W, int terms) {
+static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W, int terms, int GB = 2) {
     LstmSbShape none{};
     none.ok = false;
     if (Ch % 16 != 0 || Ch < 16) return none;
@@ -367,7 +429,7 @@ static inline LstmSbShape lstm_sb_shape(int Ch, int H, int W, int terms) {
     // the more chunks of K, the more of them a workgroup's waves split; a map whose rows do not fill the wider tile of the
     // four-way split (LDS of its four halo tiles) falls back to the next shape
     for (int kw = C16 >= 16 ? 4 : (C16 >= 8 ? 2 : 1); kw >= 1; kw >>= 1) {
-        const LstmSbShape s = lstm_sb_shape_kw(Ch, H, W, kw, terms);
+        const LstmSbShape s = lstm_sb_shape_kw(Ch, H, W, kw, terms, GB);
         if (s.ok) return s;
     }
     return none;
@@ -412,7 +474,8 @@ static const void* lstm_sb_kernel_ptr(const LstmSbShape& s, int terms) {
     return s.kw == 4 ? lstm_sb_ptr_m<1, 4, 3, 3>(s) : s.kw == 2 ? lstm_sb_ptr_m<2, 2, 2, 3>(s) : lstm_sb_ptr_m<4, 1, 2, 3>(s);
 }
 int lstm_sb_step_launch(LstmSbArgs a, int G, hipStream_t stream) {
-    const LstmSbShape s = lstm_sb_shape(a.Ch, a.H, a.W, a.terms);
+    // (the shape is chosen as for both directions, whatever this launch covers: bde_split_sweep computes what the joint launch does)
+    const LstmSbShape s = lstm_sb_shape(a.Ch, a.H, a.W, a.terms, 2 * a.B);
     if (!s.ok) return fail(BDE_ERR_UNSUPPORTED, "split recurrent step: no shape for %d channels on a %dx%d map", a.Ch, a.H, a.W);
     a.TR = s.TR; a.TC = s.TC; a.tiles_x = s.tiles_x;
     if (a.terms == 2) {

@@ -96,6 +96,23 @@ __device__ __forceinline__ void ws_split_pair_g(float x0, float x1, unsigned (&t
 #ifndef WS_ATTN_KEY_OUTER
 #define WS_ATTN_KEY_OUTER 0
 #endif
+// Packed fp32 vector math in the attention phase (v_pk_fma_f32 / v_pk_add_f32: two fp32 operations per lane and instruction, the
+// form the 157 TFLOP/s vector peak is quoted for): p . v accumulates the head's four output channels as two pairs with p broadcast
+// by op_sel, the softmax argument and the running sum likewise.  The phase is vector-issue bound (30 instructions per score tile
+// besides its one MFMA, four of them quarter-rate v_exp_f32): 18 with the packed forms.  Written as inline asm: left to the
+// vectorizer, packed arithmetic spreads into the accumulators' producers and the phase spills (see ws_pk below).
+// Measured (same box, bench.py): 2123 / 1756 frames/s (three sequences / one in flight) with the packed forms, 2151 / 1764 without:
+// no gain -- the phase waits on its dependent chains (MFMA -> max -> exp -> FMA), not on vector issue slots.  Off.
+#ifndef WS_PK_PV
+#define WS_PK_PV 0
+#endif
+// acc += p.{x|y} * v  (p broadcast from the low / high half of its register pair: the compiler folds the splat into op_sel).
+// Vector arithmetic, not inline asm: an asm consumer of a fresh v_exp_f32 result is invisible to the hazard recognizer (the
+// transcendental unit's results need a wait state before a dependent vector instruction) and read garbage.
+__device__ __forceinline__ f32x2 ws_pk_fma_lo(f32x2 p, f32x2 v, f32x2 acc) { return __builtin_elementwise_fma(f32x2{p[0], p[0]}, v, acc); }
+__device__ __forceinline__ f32x2 ws_pk_fma_hi(f32x2 p, f32x2 v, f32x2 acc) { return __builtin_elementwise_fma(f32x2{p[1], p[1]}, v, acc); }
+__device__ __forceinline__ f32x2 ws_pk_sub_bcast(f32x2 a, f32x2 m) { return a - f32x2{m[0], m[0]}; }
+__device__ __forceinline__ f32x2 ws_pk_add(f32x2 a, f32x2 b) { return a + b; }
 // two-term weights are packed times a power of two (split.h): the accumulator of GEMM i is multiplied by a.unscale[i]
 #define WS_US(x, i) (TERMS == 2 ? (x) * a.unscale[i] : (x))
 template <int TERMS>
@@ -439,6 +456,10 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                         l *= corr; o0 *= corr; o1 *= corr; o2 *= corr; o3 *= corr;
                     }
                     mx = m2;
+#if WS_PK_PV
+                    f32x2 o01 = {o0, o1}, o23 = {o2, o3}, l2 = {l, 0.f};
+                    const f32x2 mx2 = {mx, mx};
+#endif
 #pragma unroll
                     for (int j = 0; j < HT; ++j) {
                         if (j + 1 < HT) {
@@ -447,6 +468,21 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                                 vb[(j + 1) & 1][r] = *reinterpret_cast<const f32x4*>(vbase + ((hf * HT + j + 1) * 16 + r) * WB_VP);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+#if WS_PK_PV
+                        const f32x4 s4 = sc[cb][j];
+                        const f32x2 a01 = ws_pk_sub_bcast(f32x2{s4[0], s4[1]}, mx2), a23 = ws_pk_sub_bcast(f32x2{s4[2], s4[3]}, mx2);
+                        const f32x2 p01 = {__builtin_amdgcn_exp2f(a01[0]), __builtin_amdgcn_exp2f(a01[1])};
+                        const f32x2 p23 = {__builtin_amdgcn_exp2f(a23[0]), __builtin_amdgcn_exp2f(a23[1])};
+                        l2 = ws_pk_add(l2, p01);
+                        l2 = ws_pk_add(l2, p23);
+                        {
+                            const f32x4 v0 = vb[j & 1][0], v1 = vb[j & 1][1], v2 = vb[j & 1][2], v3 = vb[j & 1][3];
+                            o01 = ws_pk_fma_lo(p01, f32x2{v0[0], v0[1]}, o01); o23 = ws_pk_fma_lo(p01, f32x2{v0[2], v0[3]}, o23);
+                            o01 = ws_pk_fma_hi(p01, f32x2{v1[0], v1[1]}, o01); o23 = ws_pk_fma_hi(p01, f32x2{v1[2], v1[3]}, o23);
+                            o01 = ws_pk_fma_lo(p23, f32x2{v2[0], v2[1]}, o01); o23 = ws_pk_fma_lo(p23, f32x2{v2[2], v2[3]}, o23);
+                            o01 = ws_pk_fma_hi(p23, f32x2{v3[0], v3[1]}, o01); o23 = ws_pk_fma_hi(p23, f32x2{v3[2], v3[3]}, o23);
+                        }
+#else
                         float pr[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(sc[cb][j][r] - mx);
@@ -459,8 +495,12 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                             o2 += pr[r] * v[2];
                             o3 += pr[r] * v[3];
                         }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#if WS_PK_PV
+                    o0 = o01[0]; o1 = o01[1]; o2 = o23[0]; o3 = o23[1]; l = l2[0] + l2[1];
+#endif
                 }
                 pm[i] = mx; pl[i] = l; po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
             }

@@ -387,6 +387,7 @@ def main():
     ap.add_argument('--width', type=int, default=240)
     ap.add_argument('--batch', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-strict', action='store_true', help='skip the strict-fp32 leg (profiling runs: only the default kernels in the trace)')
     ap.add_argument('--pipeline', type=int, default=3, help='independent sequences in flight per GPU (1..4)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -491,35 +492,36 @@ def main():
         # ---- strict fp32: the same K steps with every split-operand kernel off (fp32 MFMA / fp32 vector arithmetic throughout:
         # what the path does with exact fp32 products), same number of sequences in flight, frames checked against the same fixture
         STRICT = dict(conv_sb=0, lstm_sbk=0, winblock_sb=0, wide_kv_sb=0, wide_fuse_mlp=0)
-        for k, v in STRICT.items():
-            model.set_tuning(k, v)
-        model.set_tuning('pipeline', args.pipeline)
-        for i in range(2 * args.pipeline):
-            model(inputs)
-        model.wait()
-        torch.cuda.synchronize(device)
-        barrier()
-        t2 = time.perf_counter()
-        strict_last = None
-        for _ in range(args.steps):
-            strict_last = model(inputs)
-        model.wait()
-        torch.cuda.synchronize(device)
-        barrier()
-        strict_elapsed = time.perf_counter() - t2
-        strict_ok, strict_err = None, None
-        if can_verify:
-            ok, strict_err = workload.verify_against_fixture(torch.stack(strict_last), fixture[0])
-            strict_ok = bool(min_over_ranks(1.0 if ok else 0.0, device) > 0.5)
-            strict_err = max_over_ranks(strict_err, device)
-        strict_sb = [model.get_info(k) for k in ('sb_head', 'sb_enc0', 'sb_dec0', 'sb_lstm0', 'sb_lstm2')]
-        for k in STRICT:
-            model.set_tuning(k, 1)
-        for kv in tuning.split(','):                              # (BDE_TUNING may have set one of them)
-            if '=' in kv:
-                k, v = kv.split('=')
-                model.set_tuning(k, int(v))
-        log(f'strict fp32: {args.steps * T * B / strict_elapsed:.1f} frames/s, verified={strict_ok}')
+        strict_elapsed, strict_ok, strict_err, strict_sb = float('nan'), None, None, None
+        if not args.no_strict:
+            for k, v in STRICT.items():
+                model.set_tuning(k, v)
+            model.set_tuning('pipeline', args.pipeline)
+            for i in range(2 * args.pipeline):
+                model(inputs)
+            model.wait()
+            torch.cuda.synchronize(device)
+            barrier()
+            t2 = time.perf_counter()
+            strict_last = None
+            for _ in range(args.steps):
+                strict_last = model(inputs)
+            model.wait()
+            torch.cuda.synchronize(device)
+            barrier()
+            strict_elapsed = time.perf_counter() - t2
+            if can_verify:
+                ok, strict_err = workload.verify_against_fixture(torch.stack(strict_last), fixture[0])
+                strict_ok = bool(min_over_ranks(1.0 if ok else 0.0, device) > 0.5)
+                strict_err = max_over_ranks(strict_err, device)
+            strict_sb = [model.get_info(k) for k in ('sb_head', 'sb_enc0', 'sb_dec0', 'sb_lstm0', 'sb_lstm2')]
+            for k in STRICT:
+                model.set_tuning(k, 1)
+            for kv in tuning.split(','):                              # (BDE_TUNING may have set one of them)
+                if '=' in kv:
+                    k, v = kv.split('=')
+                    model.set_tuning(k, int(v))
+            log(f'strict fp32: {args.steps * T * B / strict_elapsed:.1f} frames/s, verified={strict_ok}')
         # ---- per-kernel spans: HIP events around every launch, on the launch stream.  Events recorded inside a
         # replayed hipGraph cannot be read back, so the spans come from a few extra EAGER, un-pipelined steps
         # run right after the timed region (same inputs, same kernels).
@@ -532,7 +534,8 @@ def main():
         torch.cuda.synchronize(device)
     elapsed = max_over_ranks(elapsed, device)
     single_elapsed = max_over_ranks(single_elapsed, device)
-    strict_elapsed = max_over_ranks(strict_elapsed, device)
+    if not args.no_strict:
+        strict_elapsed = max_over_ranks(strict_elapsed, device)
     log(f'timed region done: {elapsed:.3f} s for {args.steps} steps')
 
     if rank == 0:
@@ -624,7 +627,7 @@ def main():
             'single_stream_note': (f'the same {args.steps} steps with ONE sequence in flight per GPU (pipeline 1, graph replay '
                                    f'{bool(single_graph)}): per-sequence latency, each call waits for its frames (range guard of the '
                                    'two-term format); `value` overlaps `config.pipeline` independent sequences'),
-            'strict_fp32': {'value': args.steps * T * B * world / strict_elapsed, 'unit': 'frames/s',
+            'strict_fp32': None if args.no_strict else {'value': args.steps * T * B * world / strict_elapsed, 'unit': 'frames/s',
                             'ms_per_step': 1e3 * strict_elapsed / args.steps, 'verified': strict_ok, 'max_abs_err': strict_err,
                             'pipeline': args.pipeline,
                             'what': 'the same steps with every split-operand kernel switched off (' +

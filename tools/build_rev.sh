@@ -1,11 +1,10 @@
 #!/bin/bash
-# Build the library of another git revision into ab_build/lib_<rev>.so (for same-box A/B timing:
-# BDE_LIB_PATH=ab_build/lib_<rev>.so python tools/microbench.py ...).
+# Build the library of another git revision into ab_build/lib_<name>.so (same-box A/B timing: tools/gpu.sh <tag> ab:<name>).
+#   usage: tools/build_rev.sh <rev> [name]
 set -e
-REV=$1
-mkdir -p ab_build/src_$REV
-git archive $REV bde2vid_amd/csrc include | tar -x -C ab_build/src_$REV
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden -DBDE_BUILD \
-    -o ab_build/lib_$REV.so ab_build/src_$REV/bde2vid_amd/csrc/bde_api.hip
-rm -rf ab_build/src_$REV
-echo built ab_build/lib_$REV.so
+REV=$1; NAME=${2:-$1}
+mkdir -p ab_build/src_$NAME
+git archive $REV bde2vid_amd/csrc include Makefile | tar -x -C ab_build/src_$NAME
+(cd ab_build/src_$NAME && make -s all && cp bde2vid_amd/libbde2vid.so ../lib_$NAME.so)
+rm -rf ab_build/src_$NAME
+echo built ab_build/lib_$NAME.so

@@ -13,6 +13,7 @@
 #   pmc              FETCH_SIZE / WRITE_SIZE / SQ_* counter passes (each its own run, --kernel-trace only) -> profiles/<tag>_pmc.json
 #   configs          bench lines of BASELINE configs 3 and 5 at full size     -> gpurun_out/<tag>_bench_config{3,5}.json
 #   py:<script>:<args...>    python tools/<script>.py args                    -> gpurun_out/<tag>_<script>.txt
+#   pyv:<lib>:<script>:<args...>   the same with BDE_LIB_PATH=ab_build/lib_<lib>.so
 set -o pipefail
 TAG=$1; shift
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
@@ -33,12 +34,12 @@ for step in "$@"; do
     tests:*) timeout -k 10 1000 python -m pytest tests -x -q -m gpu -k "${step#tests:}" 2>&1 | tee $O/${TAG}_pytest_k.txt | tail -15 || exit 1 ;;
     bench)   run_bench "" -- || exit 1 ;;
     bench:*) IFS=: read -r _ name args <<< "$step"; run_bench "$name" -- ${args//,/ } || exit 1 ;;
-    ab:*)    lib=${step#ab:}; run_bench "ab_$lib" BDE_LIB_PATH=$R/ab_build/lib_$lib.so BDE_LIB_ANY_ABI=1 -- --no-cpu-baseline || exit 1 ;;
-    tune:*)  IFS=: read -r _ name kv <<< "$step"; run_bench "$name" BDE_TUNING=$kv -- --no-cpu-baseline || exit 1 ;;
+    ab:*)    lib=${step#ab:}; run_bench "ab_$lib" BDE_LIB_PATH=$R/ab_build/lib_$lib.so BDE_LIB_ANY_ABI=1 -- --no-cpu-baseline --no-strict || exit 1 ;;
+    tune:*)  IFS=: read -r _ name kv <<< "$step"; run_bench "$name" BDE_TUNING=$kv -- --no-cpu-baseline --no-strict || exit 1 ;;
     prof)
       cd /tmp && export TMPDIR=/tmp
       for mode in default pipeline1; do
-        ARGS="--steps 6 --warmup 2 --no-cpu-baseline"; NF=$FRAMES_DEFAULT
+        ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-strict"; NF=$FRAMES_DEFAULT
         [ $mode = pipeline1 ] && { ARGS="$ARGS --pipeline 1"; NF=$FRAMES_P1; }
         rm -rf $O/prof_${TAG}_$mode
         timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_$mode -- python3 $R/bench.py $ARGS > $O/prof_${TAG}_$mode.log 2>&1 \
@@ -49,7 +50,7 @@ for step in "$@"; do
       cd $R; head -30 $O/${TAG}_pipeline1_summary.txt ;;
     pmc)
       cd /tmp && export TMPDIR=/tmp
-      ARGS="--pipeline 1 --steps 2 --warmup 1 --no-cpu-baseline"
+      ARGS="--pipeline 1 --steps 2 --warmup 1 --no-cpu-baseline --no-strict"
       for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
         d=pmc_${TAG}_${c%% *}; [ "${c%% *}" = SQ_WAVE_CYCLES ] && d=pmc_${TAG}_SQ
         rm -rf $O/$d; echo "[pmc] pass ${c%% *}"
@@ -62,6 +63,8 @@ for step in "$@"; do
       run_bench config5 -- --height 720 --width 1280 --seq-len 64 --steps 3 --warmup 1 --pipeline 2 --no-cpu-baseline || exit 1 ;;
     py:*)    IFS=: read -r _ script args <<< "$step"
              timeout -k 10 500 python tools/$script.py ${args//,/ } 2>&1 | tee $O/${TAG}_$script.txt | tail -40 || exit 1 ;;
+    pyv:*)   IFS=: read -r _ lib script args <<< "$step"
+             BDE_LIB_PATH=$R/ab_build/lib_$lib.so BDE_LIB_ANY_ABI=1 timeout -k 10 500 python tools/$script.py ${args//,/ } 2>&1 | tee $O/${TAG}_${script}_$lib.txt | tail -40 || exit 1 ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
