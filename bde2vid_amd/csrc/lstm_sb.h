@@ -38,6 +38,12 @@ namespace bde {
 #ifndef LSB_SWZ
 #define LSB_SWZ 1
 #endif
+// which shapes read their pixel fragments one unit ahead of the MFMAs (see the stage loop): where a wave takes all of K (level 0 of
+// config A) it costs no register; with K split two ways (level 1) it cost 40 and the third workgroup of a CU; with K split four
+// ways (level 2: two workgroups per CU) the 30 registers it costs are there
+#ifndef LSB_PIPE
+#define LSB_PIPE(KW) ((KW) != 2)
+#endif
 __host__ __device__ constexpr int lsb_slots(int terms) { return (terms == 2 && LSB_SWZ) ? 4 : sb_lds_slots(terms); }
 
 struct LstmSbArgs {
@@ -263,31 +269,54 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 #pragma unroll
                 for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(boff[t]));
             }
+            // The pixel fragments of unit u + 1 (a unit = one tap of one 32-pixel tile: two 16-byte LDS reads, three dependent MFMAs
+            // = 96 cycles) are read BEFORE the MFMAs of unit u: left to the compiler every unit was read, waited for
+            // (s_waitcnt lgkmcnt(0)) and then multiplied, an LDS round trip in front of every three MFMAs.
+            auto read_unit = [&](int u, sb8 (&b)[TERMS]) {
+                const int tap = u / NT, t = u - tap * NT;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                if constexpr (SWZ) {
+                    const int p = boff[t] + ky * IW + kx;                            // pixel of the tile this lane reads for this tap
+                    const int o0 = p * 64 + ((hl ^ ((p >> 2) & 3)) << 4);            // term 0 = pieces hl, term 1 = pieces 2 + hl: slot ^ 2
+                    b[0] = *reinterpret_cast<const sb8*>(tile + o0);
+                    b[1] = *reinterpret_cast<const sb8*>(tile + (o0 ^ 32));
+                } else {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int cur = tap % RING, nxt = (tap + PF) % RING;
-                {
+                    for (int k = 0; k < TERMS; ++k)
+                        b[k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
+                }
+            };
+            if constexpr (!LSB_PIPE(KW)) {
+                // (as the compiler orders it: every tap's fragments read, waited for, multiplied)
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int nxt = (tap + PF) % RING;
+                    const long sp = min(s * TAPS + tap + PF, S - 1);
+#pragma unroll
+                    for (int k = 0; k < TERMS; ++k) af[nxt][k] = wfr[(sp * TERMS + k) * 64];
+                    sb8 bfr[NT][TERMS];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) read_unit(tap * NT + t, bfr[t]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = sb_mma32<TERMS>(af[tap % RING], bfr[t], acc[t]);
+                }
+                continue;
+            }
+            sb8 bb[2][TERMS];
+            read_unit(0, bb[0]);
+#pragma unroll
+            for (int u = 0; u < TAPS * NT; ++u) {
+                const int tap = u / NT, t = u - tap * NT;
+                if (t == 0) {
+                    const int nxt = (tap + PF) % RING;
                     const long sp = min(s * TAPS + tap + PF, S - 1);
 #pragma unroll
                     for (int k = 0; k < TERMS; ++k) af[nxt][k] = wfr[(sp * TERMS + k) * 64];
                 }
-                const int ky = tap / 3, kx = tap - ky * 3;
-                sb8 bfr[NT][TERMS];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if constexpr (SWZ) {
-                        const int p = boff[t] + ky * IW + kx;                        // pixel of the tile this lane reads for this tap
-                        const int o0 = p * 64 + ((hl ^ ((p >> 2) & 3)) << 4);        // term 0 = pieces hl, term 1 = pieces 2 + hl: slot ^ 2
-                        bfr[t][0] = *reinterpret_cast<const sb8*>(tile + o0);
-                        bfr[t][1] = *reinterpret_cast<const sb8*>(tile + (o0 ^ 32));
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < TERMS; ++k)
-                            bfr[t][k] = *reinterpret_cast<const sb8*>(tile + boff[t] + (ky * IW + kx) * SB_LDS_PITCH + k * 32);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = sb_mma32<TERMS>(af[cur], bfr[t], acc[t]);
+                if (u + 1 < TAPS * NT) read_unit(u + 1, bb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = sb_mma32<TERMS>(af[tap % RING], bb[u & 1], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         LSB_STAMP(3);

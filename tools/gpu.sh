@@ -17,7 +17,7 @@
 set -o pipefail
 TAG=$1; shift
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-FRAMES_DEFAULT=25; FRAMES_P1=21          # forwards of `bench.py --steps 6 --warmup 2` with 3 / 1 sequences in flight (prof_summary.py)
+FRAMES_DEFAULT=23; FRAMES_P1=21          # forwards of `bench.py --steps 6 --warmup 2 --no-strict` with 2 / 1 sequences in flight (prof_summary.py)
 
 run_bench() {   # name, env assignments..., then "--" and bench arguments
   local name=$1; shift
