@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         // CU each) start a third of a stage apart instead.
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const unsigned round = (lin >> 8) % 3u;
-        for (unsigned i = 0; i < round * LSB_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);     // 127 x 64 cycles each
+        for (unsigned i = 0; i < round; ++i) __builtin_amdgcn_s_sleep(LSB_STAGGER);         // LSB_STAGGER x 64 cycles per round
     }
     LSB_STAMP(0);
     const unsigned long long real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostics: 100 MHz reference clock)

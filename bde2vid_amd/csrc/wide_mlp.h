@@ -71,11 +71,14 @@ __device__ __forceinline__ f32x4 ld_sc1_f4(const float* p) {
     return v;
 }
 
+#ifndef WM_PD
+#define WM_PD 3
+#endif
 // C = 256 channels, hidden = 1024.  grid (token tiles, 4 quarters of the hidden rows, B), 256 threads.
 __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     constexpr int NKS = 8;                 // k-steps of 32 per phase (K = 256 per workgroup in all three GEMMs)
     constexpr int NG = 3 * NKS;            // k-step groups of the wave's fragment stream
-    constexpr int PD = 3;                  // groups in flight ahead of the one being contracted
+    constexpr int PD = WM_PD;              // groups in flight ahead of the one being contracted
     constexpr int RING = PD + 1;
     __shared__ __align__(16) unsigned char X1S[NKS * 2 * 1024];   // x1 as split B fragments [k-step][term][64 lanes][16 B]
     __shared__ __align__(16) unsigned char HS[NKS * 2 * 1024];    // this quarter's hidden activations likewise
