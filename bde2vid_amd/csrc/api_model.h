@@ -194,6 +194,8 @@ struct bde_model {
     int use_lstm_sbk = 1;         // recurrent step on the 16-bit matrix cores with the pointwise tail fused (lstm_sb.h) where a shape fits
     int wide_fuse_mlp = 1;        // ... and x1 = x + proj(.) together with GELU(fc1(LN(x1))) in one launch (projfc1_sb_kernel)
     int wide_fuse_fc2 = 1;        // ... and fc2 + both residuals in the same launch (mlp_fused_kernel, wide_mlp.h): two launches per block
+    int wide_prefetch = 0;        // 1: the attention core warms the L2s with the weights of the MLP launch behind it (wide_core.h).  Measured:
+                                  // the MLP launch's first phase 13.2 k -> 12.5 k cycles, the bench 2191 -> 2124 / 1790 -> 1779 frames/s: off
     int wide_spl = 1;             // ... on frames kept as SPL16 (pre-split operand fragments + LayerNorm statistics, wide_core.h)
     int wide_core2 = 1;           // the window half of such a block as wide_core_kernel (wide_core.h): weights by LDS-DMA, K | V of the
                                   // refined neighbour frame computed inside (no K|V GEMM launch between two frames)

@@ -928,6 +928,12 @@ static int run_attention_frame_wide(bde_model* m, int l, const float* xq, const 
             a.D = D; a.C = C; a.heads = c.num_heads; a.H = H; a.W = W; a.Hp = H + ph; a.Wp = W + pw;
             a.pt = pt; a.pl = plft; a.nWw = (W + pw) / 7; a.dilated = dil ? 1 : 0; a.ntile = ntile;
             a.ovf = m->ovf();
+            if (m->wide_prefetch && will_fuse_mlp && ab.projHF >= 0 && ab.fc1N >= 0) {
+                a.pf_ptr[0] = reinterpret_cast<const unsigned char*>(m->P(ab.projHF));   // proj, two terms: 4 bytes per weight
+                a.pf_bytes[0] = 4L * C * C;
+                a.pf_ptr[1] = reinterpret_cast<const unsigned char*>(m->P(ab.fc1N));
+                a.pf_bytes[1] = 4L * 4 * C * C;
+            }
             a.stamps = m->tok_debug == 22 ? m->tok_stamps : nullptr;
             ProfScope ps(m, pname("wide_core", l), s);
             BDE_TRY(wide_core_launch(a, B, s));

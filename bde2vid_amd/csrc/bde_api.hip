@@ -385,6 +385,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "wide_spl") { m->wide_spl = (int)value; return BDE_OK; }
+    if (std::string(key) == "wide_prefetch") { m->wide_prefetch = (int)value; return BDE_OK; }
     if (std::string(key) == "conv_sb") {
         if (m->conv_sb != (int)value)
             for (auto& w : m->wslots) w.release();           // which recurrent step runs (and its buffers) depends on it

@@ -106,6 +106,11 @@ struct WideCoreArgs {
     const float *xSt, *xpSt;      // [B][ntile * 16][2]
     long spl_bs, st_bs;           // batch strides: 16-bit elements / floats
     const float* zeros;           // >= 16 bytes of zeros (operand of a padding token)
+    // L2 warm-up for the launch that follows on the chain (mlp_fused_kernel): its proj / fc1 weight fragments were last read one
+    // frame ago and have left the 4 MB L2s since.  Each workgroup touches its share of [pf_ptr, pf_ptr + pf_bytes) -- the workgroups of
+    // one XCD (every eighth in dispatch order) cover the whole range between them -- with loads nobody waits for.
+    const unsigned char* pf_ptr[2];
+    long pf_bytes[2];
 };
 #define WC_STAMP(i)                                                                                                  \
     do {                                                                                                             \
@@ -226,6 +231,20 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // one round trip for all of the above
     __syncthreads();
     WC_STAMP(1);
+    f32x4 pf_sink = {0.f, 0.f, 0.f, 0.f};     // destination of the warm-up loads: stays reserved until they have landed (end of the kernel)
+    if (a.pf_ptr[0] != nullptr && wave == 3) {
+        // (wave 3 holds one query of the window: the idlest of the four)
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned per_xcd = (gridDim.x * gridDim.y * gridDim.z + 7u) >> 3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (a.pf_ptr[r] == nullptr) continue;
+            const long share = ((a.pf_bytes[r] / per_xcd) + 1023) & ~1023L;        // whole 1-KiB wave loads
+            const long beg = (long)(lin >> 3) * share;
+            for (long o = beg + lane * 16; o < min(beg + share, a.pf_bytes[r]); o += 1024)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(pf_sink) : "v"(a.pf_ptr[r] + o) : "memory");
+        }
+    }
 
     // ---- q | k | v of this wave's token tile (query frame) and k | v of the same window tokens of the refined neighbour -------------
     f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq, akp = aq, avp = aq;
@@ -396,6 +415,8 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
         for (int r = 0; r < 4; ++r) op[r * 64] = acc[r] * inv;
     }
     WC_STAMP(6);
+    // (an asynchronous load may not outlive the reservation of its destination register)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");
 }
 
 static int wide_core_launch(const WideCoreArgs& a, int B, hipStream_t s) {

@@ -182,3 +182,52 @@ def test_tile_binning_equals_atomic_scatter():
     assert maxabs(a, b) <= 1e-4
     assert float(a[-1].abs().max()) == 0.0 and float(a[-2].abs().max()) == 0.0      # 2-event and empty windows
     assert float(a.abs().sum()) > 0
+
+
+def test_bucketed_binning_from_two_threads_on_two_streams():
+    """The scratch of the bucketed binning (records + run tables) is stream-ordered (hipMallocAsync on the caller's stream in
+    front of the call's two launches, hipFreeAsync behind them): two host threads binning different recordings on two streams
+    at the same time get the grids each of them gets alone -- with one shared buffer per device they overwrote each other's
+    records.  A NaN time stamp inside an ordinary window marks its pixel NaN in every bin on the fixed-point tile path too."""
+    import threading
+    from bde2vid_amd import _lib
+    from bde2vid_amd.events import events_to_voxel_windows
+    from bde2vid_amd.synth import synthetic_recording
+    H, W = 180, 240
+    recs = [synthetic_recording(600000 + 50000 * i, H, W, 8, 21 + i) for i in range(2)]
+    L = _lib.lib()
+    _lib.check(L.bde_voxel_method(2))                      # bucketed always
+    try:
+        ref = [events_to_voxel_windows(*r[:4], r[4], 5, sensor_size=(H, W)).clone() for r in recs]
+        torch.cuda.synchronize()
+        out = [[None] * 6 for _ in recs]
+        errs = []
+
+        def work(i):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for k in range(6):
+                        out[i][k] = events_to_voxel_windows(*recs[i][:4], recs[i][4], 5, sensor_size=(H, W))
+                st.synchronize()
+            except Exception as e:                          # noqa: BLE001 (reported below)
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            for k in range(6):
+                assert torch.equal(out[i][k], ref[i]), (i, k)
+        # a NaN time stamp in window 2 of recording 0
+        xs, ys, ts, ps, idx = recs[0]
+        ts = ts.copy()
+        j = int(idx[2]) + 1234
+        ts[j] = np.nan
+        g = events_to_voxel_windows(xs, ys, ts, ps, idx, 5, sensor_size=(H, W))
+        y, x = int(ys[j]), int(xs[j])
+        assert torch.isnan(g[2, :, y, x]).all() and int(torch.isnan(g).sum()) == 5
+    finally:
+        _lib.check(L.bde_voxel_method(0))
