@@ -86,6 +86,60 @@ __device__ __forceinline__ float wb_shfl_xor(float v, int m) { return __shfl_xor
 // vmcnt as well).
 __device__ __forceinline__ void wb_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// ---- cross-lane exchanges on the vector ALU ------------------------------------------------------------------------------------
+// __shfl_xor is ds_bpermute_b32: an LDS-pipe instruction (one per ~8 cycles for the whole CU, ~100 cycles of latency).  The attention
+// phase's merges issued ~70 of them per wave -- 1100 per window, a third of the phase (measured: the phase without its score loop
+// still took 9.3 k of 28.7 k cycles).  gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows (the upper 32
+// lanes) of one register with the even rows (the lower 32 lanes) of another: with a copy as the second operand that is the value of
+// lane ^ 16 (lane ^ 32) in one vector instruction.
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: with operands that hold equal values ROCm 7.2 reads the first result for
+// both (v_permlane16_swap v53, v50 ; v_add_f32 v50, v53, v53 -- tools/ubench/permlane_probe.hip prints the instruction's real
+// behaviour).  The s_nop covers the two wait states a vector write needs before a permlane swap reads it; the hazard recognizer does
+// not look into asm.
+__device__ __forceinline__ void wb_swap16(float& x, float& y) {         // rows 1, 3 of x <-> rows 0, 2 of y
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
+__device__ __forceinline__ void wb_swap32(float& x, float& y) {         // lanes 32..63 of x <-> lanes 0..31 of y
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
+// sum / max over the four lanes col, col + 16, col + 32, col + 48: every one of them gets the result (a + b = b + a exactly, so the
+// four copies agree bit for bit)
+__device__ __forceinline__ float wb_rows_sum(float v) {
+    float y = v;
+    wb_swap16(v, y);
+    v += y;
+    y = v;
+    wb_swap32(v, y);
+    return v + y;
+}
+__device__ __forceinline__ float wb_rows_max(float v) {
+    float y = v;
+    wb_swap16(v, y);
+    v = fmaxf(v, y);
+    y = v;
+    wb_swap32(v, y);
+    return fmaxf(v, y);
+}
+// sum / max over the 16 lanes of a row through DPP (quad xor 1, quad xor 2, mirror within 8, mirror within 16)
+template <int CTRL>
+__device__ __forceinline__ float wb_dpp(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wb_row16_sum(float v) {
+    v += wb_dpp<0xB1>(v);
+    v += wb_dpp<0x4E>(v);
+    v += wb_dpp<0x141>(v);
+    return v + wb_dpp<0x140>(v);
+}
+__device__ __forceinline__ float wb_row16_max(float v) {
+    v = fmaxf(v, wb_dpp<0xB1>(v));
+    v = fmaxf(v, wb_dpp<0x4E>(v));
+    v = fmaxf(v, wb_dpp<0x141>(v));
+    return fmaxf(v, wb_dpp<0x140>(v));
+}
+__device__ __forceinline__ float wb_wave_sum(float v) { return wb_rows_sum(wb_row16_sum(v)); }
+__device__ __forceinline__ float wb_wave_max(float v) { return wb_rows_max(wb_row16_max(v)); }
 // max of three without the quieting copies fmaxf() adds per operand (the scores are finite by construction)
 __device__ __forceinline__ float wb_max3(float a, float b, float c) {
     float d;

@@ -90,29 +90,39 @@ __device__ __forceinline__ void ws_split_pair_g(float x0, float x1, unsigned (&t
     ws_split_pair<TERMS>(x0, x1, t);
 }
 
-// Experiment switch (tools/build_variant.sh ... -DWS_ATTN_KEY_OUTER=1): key tile outermost in the attention phase, a key tile's V
-// rows read once for the three query tiles (40 LDS reads per wave instead of 120).  Measured on one box: attention phase
-// 28.8 k -> 30.7 k cycles, 32.2 -> 32.9 us per launch -- the V reads are not what the phase waits on.  Off.
-#ifndef WS_ATTN_KEY_OUTER
-#define WS_ATTN_KEY_OUTER 0
+// Measured and removed (rounds 3 / 4, same-box A/B):
+//   * key tile outermost (a key tile's V rows read once for the three query tiles, 40 LDS reads per wave instead of 120, online softmax
+//     per tile): attention phase 28.8 k -> 30.7 k cycles, 32.2 -> 32.9 us per launch -- the V reads are not what the phase waits on;
+//   * packed fp32 vector math (v_pk_fma_f32 / v_pk_add_f32 through vector builtins; as inline asm the consumers of a fresh v_exp_f32
+//     result are invisible to the hazard recognizer and read garbage): 18 instead of 30 vector instructions per score tile,
+//     2123 / 1756 frames/s against 2151 / 1764 -- no gain.
+// p . v on the matrix pipe (default): v_mfma_f32_4x4x1_16b_f32 = sixteen independent 4x4 outer products per instruction, lane 4 b + i
+// gives row i of block b's A column and column i of its B row, D[i][j] of block b sits in register i of lane 4 b + j (probe:
+// tools/ubench/mfma4x4.hip).  A score tile leaves P^T[key 4 g4 + r][query col] in register r of lane (col, g4): with a = p[r] and
+// b = V[key 4 g4 + r][channel col & 3], block (g4, col >> 2) accumulates O[query 4 (col >> 2) + i][channel j] over this lane's key
+// quarter -- four MFMAs per score tile instead of sixteen v_fma_f32, and V is read as one 16-byte LDS load per tile (four keys of one
+// channel) from a transposed image instead of four.  The per-query factors (running-maximum corrections, 1 / sum) reach the
+// transposed accumulator through quad broadcasts (DPP), the sum over the key quarters is a reduce-scatter (3 exchanges, not 8).
+// Measured (tools/win_stamps.py, one box): attention phase 27.5 k cycles against 28.1 k with the vector FMAs (-DWS_PV_MFMA=0) -- a
+// dependent 4x4x1 MFMA costs the SIMD ~12 cycles, four of them what sixteen FMAs cost; two or four independent accumulation chains
+// change nothing (28.0 k).  What it does save is registers (98 instead of 128) and 90 of the 120 V reads per wave.
+#ifndef WS_PV_MFMA
+#define WS_PV_MFMA 1
 #endif
-// Packed fp32 vector math in the attention phase (v_pk_fma_f32 / v_pk_add_f32: two fp32 operations per lane and instruction, the
-// form the 157 TFLOP/s vector peak is quoted for): p . v accumulates the head's four output channels as two pairs with p broadcast
-// by op_sel, the softmax argument and the running sum likewise.  The phase is vector-issue bound (30 instructions per score tile
-// besides its one MFMA, four of them quarter-rate v_exp_f32): 18 with the packed forms.  Written as inline asm: left to the
-// vectorizer, packed arithmetic spreads into the accumulators' producers and the phase spills (see ws_pk below).
-// Measured (same box, bench.py): 2123 / 1756 frames/s (three sequences / one in flight) with the packed forms, 2151 / 1764 without:
-// no gain -- the phase waits on its dependent chains (MFMA -> max -> exp -> FMA), not on vector issue slots.  Off.
-#ifndef WS_PK_PV
-#define WS_PK_PV 0
-#endif
-// acc += p.{x|y} * v  (p broadcast from the low / high half of its register pair: the compiler folds the splat into op_sel).
-// Vector arithmetic, not inline asm: an asm consumer of a fresh v_exp_f32 result is invisible to the hazard recognizer (the
-// transcendental unit's results need a wait state before a dependent vector instruction) and read garbage.
-__device__ __forceinline__ f32x2 ws_pk_fma_lo(f32x2 p, f32x2 v, f32x2 acc) { return __builtin_elementwise_fma(f32x2{p[0], p[0]}, v, acc); }
-__device__ __forceinline__ f32x2 ws_pk_fma_hi(f32x2 p, f32x2 v, f32x2 acc) { return __builtin_elementwise_fma(f32x2{p[1], p[1]}, v, acc); }
-__device__ __forceinline__ f32x2 ws_pk_sub_bcast(f32x2 a, f32x2 m) { return a - f32x2{m[0], m[0]}; }
-__device__ __forceinline__ f32x2 ws_pk_add(f32x2 a, f32x2 b) { return a + b; }
+// V^T [64 channels][160 keys] fp32 in the VL region; the key's tile parity is flipped by two channel bits so that the reads of a
+// wave (channels 4 h .. + 3 x four 16-byte key groups) touch 64 different banks and the q|k|v epilogue's writes conflict 2-way, not 4-way
+__device__ __forceinline__ int ws_vt(int ch, int key) { return ch * 160 + (key ^ ((((ch >> 1) ^ (ch >> 2)) & 1) << 4)); }
+template <int I>
+__device__ __forceinline__ float ws_quad_bcast(float v) {          // lane 4 q + I's value in the four lanes of quad q
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, I * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void ws_quad_scale(f32x4& o, float f) {  // o[i] *= f of lane 4 q + i
+    o[0] *= ws_quad_bcast<0>(f);
+    o[1] *= ws_quad_bcast<1>(f);
+    o[2] *= ws_quad_bcast<2>(f);
+    o[3] *= ws_quad_bcast<3>(f);
+}
 // two-term weights are packed times a power of two (split.h): the accumulator of GEMM i is multiplied by a.unscale[i]
 #define WS_US(x, i) (TERMS == 2 ? (x) * a.unscale[i] : (x))
 template <int TERMS>
@@ -240,10 +250,8 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 s2 += w[e] * w[e];
             }
         }
-        s1 += wb_shfl_xor(s1, 16);
-        s2 += wb_shfl_xor(s2, 16);
-        s1 += wb_shfl_xor(s1, 32);
-        s2 += wb_shfl_xor(s2, 32);
+        s1 = wb_rows_sum(s1);
+        s2 = wb_rows_sum(s2);
         have_tok = active && !carried;
         // fp32 copy for the residual: the query frame's tokens (tiles 0..2 and token 48), the carried pixels (tile 3,
         // columns 1..15), all four tiles of an mlp-only workgroup
@@ -320,7 +328,12 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) KL[(j * WB_C + (row0 - 64) + r) * 16 + col] = val[r];
             } else {
+#if WS_PV_MFMA
+#pragma unroll
+                for (int r = 0; r < 4; ++r) VL[ws_vt(row0 - 128 + r, u)] = val[r];
+#else
                 *reinterpret_cast<float4*>(VL + u * WB_VP + (row0 - 128)) = float4{val[0], val[1], val[2], val[3]};
+#endif
             }
         };
 #pragma unroll 1
@@ -360,15 +373,9 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             for (int i = 0; i < NQT; ++i) qf[i] = QL[(i * WB_C + h * WB_HD + g4) * 16 + col];
             const f32x4* bf = reinterpret_cast<const f32x4*>(a.biasF + (long)h * 4 * WB_NT * 256) + lane;
             constexpr int HT = WB_NT / 2;
-#if WS_ATTN_KEY_OUTER
-            f32x4 sb[2][NQT];                                          // bias of the three query tiles x (this, next) key tile
-#pragma unroll
-            for (int i = 0; i < NQT; ++i) sb[0][i] = bf[(i * WB_NT) * 64];
-#else
             f32x4 sc[2][HT];
 #pragma unroll
             for (int j = 0; j < HT; ++j) sc[0][j] = bf[j * 64];
-#endif
             float s48[4];
             {
                 const int jt = min(col, WB_NT - 1);
@@ -376,60 +383,27 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s48[r] = col < WB_NT ? b48[r] : -1e30f;
             }
-            const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
-            float pm[NQT], pl[NQT], po[NQT][4];                        // per query tile: max, sum, p*v of this lane's keys
-#if WS_ATTN_KEY_OUTER
-            // Key tile outermost: the V rows of a key tile (four 16-byte LDS reads per lane, 1 KiB per wave instruction whatever
-            // the lanes share) are fetched ONCE and used by the three query tiles -- 40 reads per wave instead of 120, the LDS
-            // return path being what the 16 waves of a window queue on.  Online softmax per (key tile, query tile): the running
-            // maximum may move at every tile (one v_exp and five multiplies more per tile than the two-halves form below).
-#pragma unroll
-            for (int i = 0; i < NQT; ++i) { pm[i] = -INFINITY; pl[i] = 0.f; po[i][0] = po[i][1] = po[i][2] = po[i][3] = 0.f; }
-            {
-                f32x4 vb[2][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vb[0][r] = *reinterpret_cast<const f32x4*>(vbase + r * WB_VP);
-#pragma unroll
-                for (int jt = 0; jt < WB_NT; ++jt) {
-                    const int cb = jt & 1, nx = cb ^ 1;
-                    if (jt + 1 < WB_NT) {
-#pragma unroll
-                        for (int i = 0; i < NQT; ++i) sb[nx][i] = bf[(i * WB_NT + jt + 1) * 64];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vb[nx][r] = *reinterpret_cast<const f32x4*>(vbase + ((jt + 1) * 16 + r) * WB_VP);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < NQT; ++i) sb[cb][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[jt], qf[i], sb[cb][i], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < NQT; ++i) {
-                        const f32x4 s4 = sb[cb][i];
-                        float m2 = wb_max3(pm[i], s4[0], s4[1]);
-                        m2 = wb_max3(m2, s4[2], s4[3]);
-                        const float corr = __builtin_amdgcn_exp2f(pm[i] - m2);          // (first tile: 2^(-inf) = 0 on zeros)
-                        pm[i] = m2;
-                        float pr[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(s4[r] - m2);
-                        float l = pl[i] * corr, o0 = po[i][0] * corr, o1 = po[i][1] * corr, o2 = po[i][2] * corr, o3 = po[i][3] * corr;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const f32x4 v = vb[cb][r];
-                            l += pr[r];
-                            o0 += pr[r] * v[0];
-                            o1 += pr[r] * v[1];
-                            o2 += pr[r] * v[2];
-                            o3 += pr[r] * v[3];
-                        }
-                        pl[i] = l; po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            float pm[NQT], pl[NQT];                                    // per query tile: max and sum over this lane's keys
+#if WS_PV_MFMA
+            // V^T rows of channel 4 h + (col & 3): keys 4 g4 .. + 3 of tile j at vte / vto + 16 j (even / odd j: ws_vt's parity flip)
+            const int vch = h * WB_HD + (col & 3);
+            const int vsw = (((vch >> 1) ^ (vch >> 2)) & 1) << 4;
+            const float* vte = VL + vch * 160 + 4 * g4 + vsw;
+            const float* vto = VL + vch * 160 + 4 * g4 - vsw;
+            auto vload = [&](int j) { return *reinterpret_cast<const f32x4*>(((j & 1) ? vto : vte) + 16 * j); };
+            f32x4 po[NQT];                                             // O[query 4 (col >> 2) + i][channel col & 3] over this lane's key quarter
 #else
+            const float* vbase = VL + (g4 * 4) * WB_VP + h * WB_HD;
+            float po[NQT][4];                                          // p*v of this lane's keys, query col
+#endif
 #pragma unroll
             for (int i = 0; i < NQT; ++i) {
-                float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                float mx = -INFINITY, l = 0.f;
+#if WS_PV_MFMA
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#else
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#endif
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int cb = hf, nx = hf ^ 1;
@@ -438,9 +412,14 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #pragma unroll
                         for (int j = 0; j < HT; ++j) sc[nx][j] = bf[(nt * HT + j) * 64];
                     }
+#if WS_PV_MFMA
+                    f32x4 vb[2];
+                    vb[0] = vload(hf * HT);
+#else
                     f32x4 vb[2][4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vb[0][r] = *reinterpret_cast<const f32x4*>(vbase + ((hf * HT) * 16 + r) * WB_VP);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < HT; ++j)
@@ -453,39 +432,36 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                     }
                     if (hf == 1) {
                         const float corr = __builtin_amdgcn_exp2f(mx - m2);
-                        l *= corr; o0 *= corr; o1 *= corr; o2 *= corr; o3 *= corr;
+                        l *= corr;
+#if WS_PV_MFMA
+                        ws_quad_scale(o, corr);
+#else
+                        o0 *= corr; o1 *= corr; o2 *= corr; o3 *= corr;
+#endif
                     }
                     mx = m2;
-#if WS_PK_PV
-                    f32x2 o01 = {o0, o1}, o23 = {o2, o3}, l2 = {l, 0.f};
-                    const f32x2 mx2 = {mx, mx};
-#endif
 #pragma unroll
                     for (int j = 0; j < HT; ++j) {
                         if (j + 1 < HT) {
+#if WS_PV_MFMA
+                            vb[(j + 1) & 1] = vload(hf * HT + j + 1);
+#else
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 vb[(j + 1) & 1][r] = *reinterpret_cast<const f32x4*>(vbase + ((hf * HT + j + 1) * 16 + r) * WB_VP);
+#endif
                         }
                         __builtin_amdgcn_sched_barrier(0);
-#if WS_PK_PV
-                        const f32x4 s4 = sc[cb][j];
-                        const f32x2 a01 = ws_pk_sub_bcast(f32x2{s4[0], s4[1]}, mx2), a23 = ws_pk_sub_bcast(f32x2{s4[2], s4[3]}, mx2);
-                        const f32x2 p01 = {__builtin_amdgcn_exp2f(a01[0]), __builtin_amdgcn_exp2f(a01[1])};
-                        const f32x2 p23 = {__builtin_amdgcn_exp2f(a23[0]), __builtin_amdgcn_exp2f(a23[1])};
-                        l2 = ws_pk_add(l2, p01);
-                        l2 = ws_pk_add(l2, p23);
-                        {
-                            const f32x4 v0 = vb[j & 1][0], v1 = vb[j & 1][1], v2 = vb[j & 1][2], v3 = vb[j & 1][3];
-                            o01 = ws_pk_fma_lo(p01, f32x2{v0[0], v0[1]}, o01); o23 = ws_pk_fma_lo(p01, f32x2{v0[2], v0[3]}, o23);
-                            o01 = ws_pk_fma_hi(p01, f32x2{v1[0], v1[1]}, o01); o23 = ws_pk_fma_hi(p01, f32x2{v1[2], v1[3]}, o23);
-                            o01 = ws_pk_fma_lo(p23, f32x2{v2[0], v2[1]}, o01); o23 = ws_pk_fma_lo(p23, f32x2{v2[2], v2[3]}, o23);
-                            o01 = ws_pk_fma_hi(p23, f32x2{v3[0], v3[1]}, o01); o23 = ws_pk_fma_hi(p23, f32x2{v3[2], v3[3]}, o23);
-                        }
-#else
                         float pr[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(sc[cb][j][r] - mx);
+#if WS_PV_MFMA
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            l += pr[r];
+                            o = __builtin_amdgcn_mfma_f32_4x4x1f32(pr[r], vb[j & 1][r], o, 0, 0, 0);
+                        }
+#else
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const f32x4 v = vb[j & 1][r];
@@ -498,13 +474,14 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
 #endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#if WS_PK_PV
-                    o0 = o01[0]; o1 = o01[1]; o2 = o23[0]; o3 = o23[1]; l = l2[0] + l2[1];
-#endif
                 }
-                pm[i] = mx; pl[i] = l; po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
-            }
+                pm[i] = mx; pl[i] = l;
+#if WS_PV_MFMA
+                po[i] = o;
+#else
+                po[i][0] = o0; po[i][1] = o1; po[i][2] = o2; po[i][3] = o3;
 #endif
+            }
             // ---- query 48: keys on the lanes ----------------------------------------------------------
             float l48, o48[4];
             {
@@ -516,32 +493,70 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) s48[r] += q48[c] * KL[(jt * WB_C + h * WB_HD + c) * 16 + g4 * 4 + r];
-                float m48 = wb_max3(s48[0], s48[1], fmaxf(s48[2], s48[3]));
-#pragma unroll
-                for (int sh = 1; sh < 64; sh <<= 1) m48 = fmaxf(m48, wb_shfl_xor(m48, sh));
+                const float m48 = wb_wave_max(wb_max3(s48[0], s48[1], fmaxf(s48[2], s48[3])));
                 l48 = 0.f;
                 o48[0] = o48[1] = o48[2] = o48[3] = 0.f;
+#if WS_PV_MFMA
+                f32x4 v48[4];                      // [channel][key 4 g4 + r of tile jt]
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v48[c] = *reinterpret_cast<const f32x4*>(VL + ws_vt(h * WB_HD + c, jt * 16 + g4 * 4));
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pr = __builtin_amdgcn_exp2f(s48[r] - m48);
+#if WS_PV_MFMA
+                    const float v[4] = {v48[0][r], v48[1][r], v48[2][r], v48[3][r]};
+#else
                     const f32x4 v = *reinterpret_cast<const f32x4*>(VL + (jt * 16 + g4 * 4 + r) * WB_VP + h * WB_HD);
+#endif
                     l48 += pr;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) o48[c] += pr * v[c];
                 }
+                l48 = wb_wave_sum(l48);
 #pragma unroll
-                for (int sh = 1; sh < 64; sh <<= 1) {
-                    l48 += wb_shfl_xor(l48, sh);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o48[c] += wb_shfl_xor(o48[c], sh);
-                }
+                for (int c = 0; c < 4; ++c) o48[c] = wb_wave_sum(o48[c]);
             }
             // merge the four key quarters of each query (lanes col, col+16, col+32, col+48)
             float M[NQT], f[NQT];
 #pragma unroll
-            for (int i = 0; i < NQT; ++i) M[i] = fmaxf(pm[i], wb_shfl_xor(pm[i], 16));
+            for (int i = 0; i < NQT; ++i) M[i] = wb_rows_max(pm[i]);
+#if WS_PV_MFMA
+            // register ii of po[i] belongs to query 4 (col >> 2) + ii: its quarter's factor comes from that lane of the quad.  The sum over
+            // the quarters is a reduce-scatter (3 exchanges instead of 8): lane (col, g4) ends with query 4 (col >> 2) + g4, channel col & 3.
+            float gm_o = 0.f;
 #pragma unroll
-            for (int i = 0; i < NQT; ++i) M[i] = fmaxf(M[i], wb_shfl_xor(M[i], 32));
+            for (int i = 0; i < NQT; ++i) {
+                f[i] = __builtin_amdgcn_exp2f(pm[i] - M[i]);
+                const float lsum = wb_rows_sum(pl[i] * f[i]);          // the query's softmax denominator (the same in its four lanes)
+                ws_quad_scale(po[i], f[i] * __builtin_amdgcn_rcpf(lsum));
+                // lanes 0..31 keep queries 4 (col >> 2) + {0, 1}, lanes 32..63 + {2, 3}; then even rows the first of the two, odd rows the second
+                float x0 = po[i][0], x1 = po[i][1], y0 = po[i][2], y1 = po[i][3];
+                wb_swap32(x0, y0);
+                wb_swap32(x1, y1);
+                float k0 = x0 + y0, k1 = x1 + y1;
+                wb_swap16(k0, k1);
+                const float kk = k0 + k1;
+                unsigned t[TERMS];
+                ws_split_pair_g<TERMS>(kk, 0.f, t, gm_o);
+                unsigned char* ao = XS + i * WS_XS_TILE + (h >> 1) * 256 + (4 * (col >> 2) + g4) * 16 + (h & 1) * 8 + (col & 3) * 2;
+#pragma unroll
+                for (int k = 0; k < TERMS; ++k) *reinterpret_cast<unsigned short*>(ao + k * WS_XS_TERM) = (unsigned short)t[k];
+            }
+            if (TERMS == 2) sb_guard_flush(gm_o, a.ovf);
+            if (lane < 16) {
+                // token tile 3: column 0 = query 48, the other columns carry no attention output
+                unsigned char* ao = XS + (h >> 1) * 256 + lane * 16 + (h & 1) * 8;
+                float gm = 0.f;
+                const float inv48 = 1.f / l48;
+                unsigned t[2][TERMS];
+                ws_split_pair_g<TERMS>(lane == 0 ? o48[0] * inv48 : 0.f, lane == 0 ? o48[1] * inv48 : 0.f, t[0], gm);
+                ws_split_pair_g<TERMS>(lane == 0 ? o48[2] * inv48 : 0.f, lane == 0 ? o48[3] * inv48 : 0.f, t[1], gm);
+#pragma unroll
+                for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + 3 * WS_XS_TILE) = uint2{t[0][k], t[1][k]};
+                if (TERMS == 2) sb_guard_flush(gm, a.ovf);
+            }
+#else
 #pragma unroll
             for (int i = 0; i < NQT; ++i) {
                 f[i] = __builtin_amdgcn_exp2f(pm[i] - M[i]);
@@ -551,15 +566,9 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < NQT; ++i) {
-                pl[i] += wb_shfl_xor(pl[i], 16);
+                pl[i] = wb_rows_sum(pl[i]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) po[i][c] += wb_shfl_xor(po[i][c], 16);
-            }
-#pragma unroll
-            for (int i = 0; i < NQT; ++i) {
-                pl[i] += wb_shfl_xor(pl[i], 32);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) po[i][c] += wb_shfl_xor(po[i][c], 32);
+                for (int c = 0; c < 4; ++c) po[i][c] = wb_rows_sum(po[i][c]);
             }
             if (lane < 16) {
                 // the head's four output channels of a token = half of operand chunk h >> 1: 8 bytes per term, already split
@@ -583,6 +592,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 for (int k = 0; k < TERMS; ++k) *reinterpret_cast<uint2*>(ao + k * WS_XS_TERM + 3 * WS_XS_TILE) = uint2{t[0][k], t[1][k]};
                 if (TERMS == 2) sb_guard_flush(gm, a.ovf);
             }
+#endif
             // proj fragments: requested only now -- the phase above sits at the 128-register cap, and a spilled register there costs
             // more than this load's latency (part of it passes in the barrier)
             {
@@ -634,10 +644,8 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 s2 += v * v;
             }
             // LayerNorm2 sums over this wave's 16 rows; the four row tiles are added in a fixed order by fc1
-            s1 += wb_shfl_xor(s1, 16);
-            s2 += wb_shfl_xor(s2, 16);
-            s1 += wb_shfl_xor(s1, 32);
-            s2 += wb_shfl_xor(s2, 32);
+            s1 = wb_rows_sum(s1);
+            s2 = wb_rows_sum(s2);
             if (lane < 16) {
                 S2[(rt * 64 + i * 16 + col) * 2] = s1;
                 S2[(rt * 64 + i * 16 + col) * 2 + 1] = s2;
