@@ -245,14 +245,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     const int tile_bytes = nblk * 1024;                    // one halo buffer
     auto stage = [&](int c16) {
         const unsigned char* cb = inb + c16 * plane;
-        unsigned char* dstb = sb_lds + (DB ? (c16 & 1) * tile_bytes : 0);
+        const unsigned dstb = sb_dyn_lds_base() + (DB ? (c16 & 1) * tile_bytes : 0);
 #pragma unroll
         for (int it = 0; it < MAXI; ++it) {
             const int blk = wave_u + it * NW;
             if (blk < nblk) {
                 const unsigned char* src = ((vmask >> it) & 1u) ? cb + goff[it] : zero16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dstb + blk * 1024), 16, 0, 0);
+                sb_lds_dma16(src, dstb + blk * 1024);       // (asm: invisible to the compiler's wait counting, split.h)
             }
         }
     };
@@ -294,8 +293,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             // (the barrier as asm with a memory clobber: the intrinsic is IntrNoMem, LDS reads or the next stage's DMA may not cross it)
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TERMS * PF * MT) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (DB && c16 + 1 < C16) stage(c16 + 1);            // (every wave left the other buffer before that barrier)
 #pragma unroll
@@ -308,6 +306,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
 #pragma unroll
                     for (int k = 0; k < TERMS; ++k) af[nxt][m][k] = wfr[m][(sp * TERMS + k) * 64];
             }
+            // The prefetch stays HERE: left alone, the scheduler sinks every fragment load to just in front of the tap that uses
+            // it (fewer live registers, one more wave per SIMD) -- ISA of round 4: `global_load; s_waitcnt vmcnt(0); v_mfma` at
+            // every tap, an L2 round trip in front of each six MFMAs.
+            __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / KS, kx = tap - ky * KS;
             sb8 bfr[NT][TERMS];
 #pragma unroll
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[m][t] = sb_mma32<TERMS>(af[cur][m], bfr[t], acc[m][t]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const float unscale = TERMS == 2 ? a.acc_scale[0] : 1.f;     // two-term weights are packed times a power of two

@@ -80,7 +80,7 @@ struct LstmSbArgs {
 #define LSB_PFK 8
 #endif
 #ifndef LSB_COUNTED_WAIT
-#define LSB_COUNTED_WAIT 0
+#define LSB_COUNTED_WAIT 1
 #endif
 #ifndef LSB_STAGGER
 #define LSB_STAGGER 0
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         const unsigned char* zero16 = reinterpret_cast<const unsigned char*>(a.zeros);
         const int set_bytes = KW * tile_bytes;            // one set of halo tiles (all parts of K)
         auto stage = [&](int s) {
-            unsigned char* dst = lsb + (DB ? (s & 1) * set_bytes : 0);
+            const unsigned dst = sb_dyn_lds_base() + (DB ? (s & 1) * set_bytes : 0);
 #pragma unroll
             for (int it = 0; it < MAXI; ++it) {
                 const int blk = wave + it * 4;
@@ -223,8 +223,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
                     const int chunk = part * stages + s;
                     const unsigned char* cb = chunk < XC ? xb + (long)chunk * plane : inb + (long)(chunk - XC) * plane;
                     const unsigned char* src = ((vmask >> it) & 1u) ? cb + goff[it] : zero16;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
+                    sb_lds_dma16(src, dst + blk * 1024);       // (asm: invisible to the compiler's wait counting, split.h)
                 }
             }
         };
@@ -240,27 +239,27 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         const sb8* wfr = reinterpret_cast<const sb8*>(a.wpk + g * a.w_gs) +
                          (((long)min(rt, nrt - 1) * KC + (long)kp * stages) * TAPS * TERMS) * 64 + lane;
         sb8 af[RING][TERMS];
+        if (DB) stage(0);                                // BEFORE the fragment prefetch: the counted wait below relies on the DMA being older
 #pragma unroll
         for (int q = 0; q < PF; ++q)
 #pragma unroll
             for (int k = 0; k < TERMS; ++k) af[q][k] = wfr[((long)min(q, S - 1) * TERMS + k) * 64];
         LSB_STAMP(1);
-        if (DB) stage(0);
         for (int s = 0; s < stages; ++s) {
             if (!DB) {
                 __syncthreads();                         // every wave is done with the previous stage's tiles
                 stage(s);
             }
-            if (s == stages - 1) epi_load();             // the tail's operands travel during the last stage
-            if (LSB_COUNTED_WAIT && DB && s > 0 && s < stages - 1) {
-                // stage s was requested before the PF taps of weight fragments that are still in flight: the counted wait covers
-                // it and leaves them alone; the barrier as asm (memory clobber: LDS reads may not cross it)
+            if (LSB_COUNTED_WAIT && DB) {
+                // The tiles of stage s were requested before the last PF taps of weight fragments, which are all that may still be in
+                // flight: the counted wait covers the tiles (loads return in order) and leaves the ring alone; the barrier as asm
+                // (memory clobber: LDS reads may not cross it)
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PF * TERMS) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                         // stage s has landed for every wave (and, DB: stage s - 1's tiles are free)
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stage s has landed for every wave (and, DB: stage s - 1's tiles are free)
             }
             if (DB && s + 1 < stages) stage(s + 1);
+            if (s == stages - 1) epi_load();             // the tail's operands travel during the last stage
             const unsigned char* tile = lsb + (DB ? (s & 1) * set_bytes : 0) + kp * tile_bytes;
             if (s == 0) LSB_STAMP(2);
             if constexpr (SWZ) {

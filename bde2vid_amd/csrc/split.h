@@ -113,6 +113,25 @@ __device__ __forceinline__ void sb_guard_flush(float gm, unsigned* flag) {
     if (flag != nullptr && gm >= SB_F16_LIMIT) atomicOr(flag, 1u);
 }
 
+// ---- LDS-DMA the waitcnt pass does not see ------------------------------------------------------------------------------------------
+// 16 bytes per lane, global -> LDS, block of 1 KiB at the WAVE-UNIFORM LDS address `lds_addr` (lane l lands at lds_addr + 16 l).  As the
+// builtin (__builtin_amdgcn_global_load_lds) the instruction makes SIInsertWaitcnts give up counting: the first wait on ANY load
+// after it becomes s_waitcnt vmcnt(0) lgkmcnt(0), which drains a register ring of weight fragments that was meant to stay in
+// flight (ISA of lstm_sb_step_kernel, round 4: one full L2 round trip per stage in the middle of the tap loop).  As inline asm the
+// compiler does not know the load exists: its own counted waits stay counted (and, loads returning in order, only ever wait for
+// MORE than they need when such a DMA is older than the load they want); whoever reads the tile waits for it by hand
+// (s_waitcnt vmcnt(n) + s_barrier as asm with a memory clobber).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void sb_lds_dma16(const void* src, unsigned lds_addr) {
+    // (readfirstlane: an "s" operand the compiler cannot prove uniform would be handed over in a VGPR)
+    const unsigned m = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
+}
+// LDS address of byte 0 of a kernel's `extern __shared__` array (it follows the kernel's static LDS)
+__device__ __forceinline__ unsigned sb_dyn_lds_base() { return __builtin_amdgcn_groupstaticsize(); }
+#pragma clang diagnostic pop
+
 // device-side splits on the conversion instructions
 __device__ __forceinline__ void split2_dev(float x, unsigned short& hi, unsigned short& lo) {
     const _Float16 h = (_Float16)x;
