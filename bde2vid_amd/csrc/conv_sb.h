@@ -208,6 +208,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             boff[t] = ((y - y_first) * STRIDE * IW + (x * STRIDE - PAD - ix0)) * SB_LDS_PITCH + hl * 16;
         }
     }
+    // (the accumulator scale is requested HERE, not behind the K loop where it is used: there it was a dependent load and a
+    //  vmcnt(0) at the end of every workgroup)
+    const float unscale_v = TERMS == 2 ? a.acc_scale[0] : 1.f;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -324,7 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const float unscale = TERMS == 2 ? a.acc_scale[0] : 1.f;     // two-term weights are packed times a power of two
+    // two-term weights are packed times a power of two (readfirstlane: into a scalar register, and the wait for it sits here)
+    const float unscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, unscale_v)));
     float fin[MT][NT][16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)

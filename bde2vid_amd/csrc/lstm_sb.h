@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         const int cy = min(py, a.TR - 1), cx = min(px, a.TC - 1);   // (dead lanes read inside the tile)
         boff[t] = SWZ ? cy * IW + cx : (cy * IW + cx) * SB_LDS_PITCH + hl * 16;      // (swizzled: the pixel index, see the tap loop)
     }
+    // (the accumulator scale is requested HERE, not in the tail where it is used: there it was a dependent load + vmcnt(0))
+    const float unscale_v = TERMS == 2 ? a.acc_scale[0] : 1.f;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     // ---- sum over the parts of K: every wave leaves its accumulators in LDS, wave (row tile, kp) collects register groups
     //      kp * QW .. of its row tile from the KW waves of that row tile -----------------------------------------------------
     float gsum[NT][QW][4];
-    const float unscale = TERMS == 2 ? a.acc_scale[0] : 1.f;     // two-term weights are packed times a power of two
+    // two-term weights are packed times a power of two (readfirstlane: into a scalar register)
+    const float unscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, unscale_v)));
     if (KW > 1 && kchunks > 0) {
         float* red = reinterpret_cast<float*>(lsb);      // [wave][tile][reg][64 lanes]
 #pragma unroll

@@ -170,14 +170,16 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t) bqS[ks][t] = sq[(ks * 2 + t) * stride];
-        if (live) stq = *reinterpret_cast<const float2*>(a.xSt + b * a.st_bs + (long)qpix * 2);
+        // (pointer select + unconditional load: a load under a per-lane branch is joined by s_waitcnt vmcnt(0) -- here a full round
+        //  trip in front of the second half of the prologue's requests; a padding token reads (0, 0) and takes rstd = 1 where it is used)
+        stq = *reinterpret_cast<const float2*>(live ? a.xSt + b * a.st_bs + (long)qpix * 2 : reinterpret_cast<const float*>(a.zeros));
         if constexpr (PREV) {
             const sb8* sp = live ? reinterpret_cast<const sb8*>(a.xpS + b * a.spl_bs) + so : reinterpret_cast<const sb8*>(a.zeros);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) bpS[ks][t] = sp[(ks * 2 + t) * stride];
-            if (live) stp = *reinterpret_cast<const float2*>(a.xpSt + b * a.st_bs + (long)qpix * 2);
+            stp = *reinterpret_cast<const float2*>(live ? a.xpSt + b * a.st_bs + (long)qpix * 2 : reinterpret_cast<const float*>(a.zeros));
         }
     } else {
 #pragma unroll
@@ -209,6 +211,14 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
         if (PREV && u >= s_hi * ATT_TOK) u += ATT_TOK;
         return u;
     };
+    // The per-slot arguments as opaque scalars: indexed by the per-lane d -- or picked by selects the compiler folds back into a
+    // load from a selected address -- they are vector loads from the kernel-argument segment, dependent round trips in front of
+    // the gathers (ISA of round 4).  D * 49 <= 160: three slots.
+    const float* kv_s[3] = {a.kv[0], a.kv[1], a.kv[2]};
+    long bs_s[3] = {a.kv_bs[0], a.kv_bs[1], a.kv_bs[2]};
+    int ld_s[3] = {a.kv_ld[0], a.kv_ld[1], a.kv_ld[2]}, ko_s[3] = {a.k_off[0], a.k_off[1], a.k_off[2]}, vo_s[3] = {a.v_off[0], a.v_off[1], a.v_off[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+s"(kv_s[i]), "+s"(bs_s[i]), "+s"(ld_s[i]), "+s"(ko_s[i]), "+s"(vo_s[i]));
     wf4 kk[GIT], vv[GIT];
 #pragma unroll
     for (int t = 0; t < GIT; ++t) {
@@ -216,20 +226,27 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
         const int u = gather_key(item), cg = item & 3;
         const int d = min(u / ATT_TOK, a.D - 1), tok = u - (u / ATT_TOK) * ATT_TOK;
         const int pix = u < nkey ? token_pixel(tok) : -1;
-        const float* kp = u < nkey ? a.kv[d] : nullptr;
+        auto pick = [&](const auto& arr) { return d == 0 ? arr[0] : (d == 1 ? arr[1] : arr[2]); };
+        const float* kp = u < nkey ? pick(kv_s) : nullptr;
         const bool use = pix >= 0 && kp != nullptr;
-        const float* ksrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.k_off[d] + c0 + cg * 4 : a.kvpad + c0 + cg * 4;
-        const float* vsrc = use ? kp + b * a.kv_bs[d] + (long)pix * a.kv_ld[d] + a.v_off[d] + c0 + cg * 4 : a.kvpad + a.C + c0 + cg * 4;
-        kk[t] = *reinterpret_cast<const wf4*>(ksrc);
-        vv[t] = *reinterpret_cast<const wf4*>(vsrc);
+        const long rowo = b * pick(bs_s) + (long)pix * pick(ld_s);
+        const float* ksrc = use ? kp + rowo + pick(ko_s) + c0 + cg * 4 : a.kvpad + c0 + cg * 4;
+        const float* vsrc = use ? kp + rowo + pick(vo_s) + c0 + cg * 4 : a.kvpad + a.C + c0 + cg * 4;
+        typedef const __attribute__((address_space(1))) wf4 gwf4;   // (explicitly global: pointers out of an opaque asm operand are generic)
+        kk[t] = *(gwf4*)reinterpret_cast<const wf4*>(ksrc);
+        vv[t] = *(gwf4*)reinterpret_cast<const wf4*>(vsrc);
     }
-    if (tid < 24) {                                                   // bias and row sums of rows c0 .. c0 + 15 of q, k, v
-        const int which = tid / 12, i = tid - which * 12, r = i >> 2, q4 = i & 3;
-        const float* src = (which ? a.sqkv : a.bqkv) + r * a.C + c0 + q4 * 4;
-        *reinterpret_cast<float4*>(PR + which * 48 + r * 16 + q4 * 4) = *reinterpret_cast<const float4*>(src);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // one round trip for all of the above
+    // bias and row sums of rows c0 .. c0 + 15 of q, k, v: 24 float4, loaded by every thread (index clamped) so that the load is
+    // not under a per-lane branch (whose join is a vmcnt(0) of its own), stored to LDS behind the one wait
+    // (the accumulator scale of the q|k|v weights rides in the same round trip: read where it is used, behind the GEMM phase, it
+    //  was a dependent kernarg load + global load + vmcnt(0) of its own in every launch -- ISA of round 4)
+    const float us_v = a.wqkv_unscale[0];
+    const int pr_t = min(tid, 23), pr_which = pr_t / 12, pr_i = pr_t - pr_which * 12;
+    wf4 prv = *reinterpret_cast<const wf4*>((pr_which ? a.sqkv : a.bqkv) + (pr_i >> 2) * a.C + c0 + (pr_i & 3) * 4);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(prv)::"memory");        // one round trip for all of the above
+    if (tid < 24) *reinterpret_cast<wf4*>(PR + pr_which * 48 + (pr_i >> 2) * 16 + (pr_i & 3) * 4) = prv;
     __syncthreads();
+    const float us_qkv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, us_v)));
     WC_STAMP(1);
     f32x4 pf_sink = {0.f, 0.f, 0.f, 0.f};     // destination of the warm-up loads: stays reserved until they have landed (end of the kernel)
     if (a.pf_ptr[0] != nullptr && wave == 3) {
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
     WC_STAMP(2);
     wf4 qv;
     {
-        const float us = a.wqkv_unscale[0];
+        const float us = us_qkv;
         auto stats = [&](float u1, float u2, float& mean, float& rstd) {
             u1 += __shfl_xor(u1, 16); u2 += __shfl_xor(u2, 16);
             u1 += __shfl_xor(u1, 32); u2 += __shfl_xor(u2, 32);
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
             rstd = __builtin_amdgcn_rsqf(fmaxf(u2 / (float)a.C - mean * mean, 0.f) + 1e-5f);
         };
         float mean, rstd;
-        if constexpr (SPL) { mean = stq.x; rstd = stq.y; }
+        if constexpr (SPL) { mean = stq.x; rstd = qpix >= 0 ? stq.y : 1.f; }
         else stats(s1, s2, mean, rstd);
         float kq[4], vq[4];
 #pragma unroll
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
         }
         if constexpr (PREV) {
             float meanp, rstdp;
-            if constexpr (SPL) { meanp = stp.x; rstdp = stp.y; }
+            if constexpr (SPL) { meanp = stp.x; rstdp = qpix >= 0 ? stp.y : 1.f; }
             else stats(p1, p2, meanp, rstdp);
             if (qi < ATT_TOK) {
                 const int u = a.p_slot * ATT_TOK + qi;

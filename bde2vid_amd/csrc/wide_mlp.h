@@ -91,6 +91,11 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     const int tile = blockIdx.x, quarter = blockIdx.y, b = blockIdx.z;
     const int tok = tile * 16 + col;
     WM_STAMP(0);
+    // The accumulator scales of the three GEMMs (split.h) are requested FIRST and turned into scalars behind the first fragment
+    // groups (a counted wait: they are the oldest loads).  Read where they are used -- the end of a phase -- each was the YOUNGEST
+    // load in flight, and the wait for it (vmcnt(0), ISA of round 4) drained the whole fragment ring twice per launch.
+    const float us_proj_v = a.unscale_proj[0], us_fc1_v = a.unscale_mlp[0], us_fc2_v = a.unscale_mlp[1];
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- operands that do not depend on anything computed here: all requested before the first MFMA ------------------------------
     // Every workgroup of a launch streams the same weight bytes (all of them proj, the 44 of a quarter its fc1 / fc2 rows) and
@@ -137,6 +142,10 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     };
     static_for<0, PD>(fetch);
     __builtin_amdgcn_sched_barrier(0);
+    const float us_proj = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, us_proj_v)));
+    const float us_fc1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, us_fc1_v)));
+    const float us_fc2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, us_fc2_v)));
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x4 acc[4];
     float x1v[4][4];                       // x1 of this wave's rows (= the rows of its fc2 output tiles)
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
                 const int rr = y + a.mask_pt, cc = x + a.mask_pl;
                 covered = !((rr < 7 && (rr & 1)) || (cc < 7 && (cc & 1)));
             }
-            const float us = a.unscale_proj[0];
+            const float us = us_proj;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
         }
         if constexpr (ks == NKS - 1 && ph == 1) {
             // hidden = GELU(fc1(LayerNorm2(x1))), rows 256 quarter + 64 wave + 16 m + 4 g4 + r
-            const float us = a.unscale_mlp[0];
+            const float us = us_fc1;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int hrt = 4 * wave + m;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
 
     // ---- this quarter's share of x2 (quarter 0 carries x1 and the bias) -> scratch, 16-byte sc1 stores ----------------------------
     {
-        const float us = a.unscale_mlp[1];
+        const float us = us_fc2;
         float* pq = a.part + ((((long)quarter * a.B + b) * a.ntile + tile) * 16 + 4 * wave) * 256 + lane * 4;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {

@@ -124,7 +124,7 @@ __device__ __forceinline__ void ws_quad_scale(f32x4& o, float f) {  // o[i] *= f
     o[3] *= ws_quad_bcast<3>(f);
 }
 // two-term weights are packed times a power of two (split.h): the accumulator of GEMM i is multiplied by a.unscale[i]
-#define WS_US(x, i) (TERMS == 2 ? (x) * a.unscale[i] : (x))
+#define WS_US(x, i) (TERMS == 2 ? (x) * us_s[i] : (x))
 template <int TERMS>
 __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -162,16 +162,29 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 aqw[ks][k] = wq[((rtq * 2 + ks) * TERMS + k) * 64];
             }
     }
-    for (int i = tid; i < 1024; i += 1024) {
-        float v;
-        if (i < 192) v = a.bqkv[i];
-        else if (i < 384) v = a.sqkv[i - 192];
-        else if (i < 448) v = a.bproj[i - 384];
-        else if (i < 704) v = a.bfc1[i - 448];
-        else if (i < 960) v = a.sfc1[i - 704];
-        else v = a.bfc2[i - 960];
-        PR[i] = v;
+    // Everything below is requested in ONE round trip.  (ISA of round 4: the six-way `if` that filled PR was six loads under
+    // per-lane branches, each joined by s_waitcnt vmcnt(0); a.unscale[i] read where it is used was a load + vmcnt(0) inside the
+    // GEMM phases; a.slot[sl] / a.rowsA[ri] indexed by a per-lane value are vector loads from the kernel-argument segment in front
+    // of the token loads -- nine dependent round trips before the first token arrived.)
+    float us_v[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (TERMS == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) us_v[i] = a.unscale[i];
     }
+    float pr_v;
+    {
+        const int i = tid;                          // 1024 threads, 1024 values: pointer select, one unconditional load
+        const float* src = i < 192 ? a.bqkv + i : i < 384 ? a.sqkv + (i - 192) : i < 448 ? a.bproj + (i - 384)
+                         : i < 704 ? a.bfc1 + (i - 448) : i < 960 ? a.sfc1 + (i - 704) : a.bfc2 + (i - 960);
+        pr_v = *src;
+    }
+    // the per-slot and uncovered-pixel arguments as opaque scalars, picked by selects (D <= 3 slots, <= 3 rows / columns)
+    const float* slot_s[3] = {a.slot[0], a.slot[1], a.slot[2]};
+    long slot_bs_s[3] = {a.slot_bs[0], a.slot_bs[1], a.slot_bs[2]};
+    int rowsA_s[3] = {a.rowsA[0], a.rowsA[1], a.rowsA[2]}, colsB_s[3] = {a.colsB[0], a.colsB[1], a.colsB[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+s"(slot_s[i]), "+s"(slot_bs_s[i]), "+s"(rowsA_s[i]), "+s"(colsB_s[i]));
+    auto pick3 = [](const auto& arr, int i) { return i == 0 ? arr[0] : (i == 1 ? arr[1] : arr[2]); };
 
     // ---- gather: wave = token tile, lane = (token col, quarter g4): channels 8 g4 .. + 7 and 32 + 8 g4 .. + 7 (chunks g4, 4 + g4) ----
     // waves 0..9: the window's tokens of all frames (query frame first); wave 10: pixels outside every dilated window
@@ -184,15 +197,16 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             int y, x;
             if (e < a.nA) {
                 const int ri = e / a.W;
-                y = a.rowsA[ri];
+                y = pick3(rowsA_s, ri);
                 x = e - ri * a.W;
             } else {
                 const int e2 = e - a.nA;
                 const int yi = e2 / a.ncolsB;
-                x = a.colsB[e2 - yi * a.ncolsB];
+                x = pick3(colsB_s, e2 - yi * a.ncolsB);
                 y = yi;
-                for (int k = 0; k < a.nrowsA; ++k)
-                    if (y >= a.rowsA[k]) ++y;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (k < a.nrowsA && y >= rowsA_s[k]) ++y;
             }
             return y * a.W + x;
         };
@@ -230,11 +244,13 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
             if (carried) PIX[WB_TOK + col] = pix;
             else if (u < 64 && (mlp_only || u < WB_TOK)) PIX[u] = pix;
         }
-        const float* sp = a.slot[sl];
+        const float* sp = pick3(slot_s, sl);
         const bool live = active && pix >= 0 && sp != nullptr;
         // pointer select + unconditional loads (a load under a per-lane branch costs a vmcnt(0) join)
-        const float4* src = reinterpret_cast<const float4*>(live ? sp + b * a.slot_bs[sl] + (long)pix * WB_C : a.slot[0]);
-        float4 v[4];
+        // (explicitly global: a pointer that went through an opaque asm operand is a generic one, and its loads flat_load)
+        typedef const __attribute__((address_space(1))) f32x4 gf4;
+        gf4* src = (gf4*)reinterpret_cast<const f32x4*>(live ? sp + b * pick3(slot_bs_s, sl) + (long)pix * WB_C : slot_s[0]);
+        f32x4 v[4];
         v[0] = src[live ? 2 * g4 : 0];
         v[1] = src[live ? 2 * g4 + 1 : 0];
         v[2] = src[live ? 8 + 2 * g4 : 0];
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const float w[4] = {live ? v[f].x : 0.f, live ? v[f].y : 0.f, live ? v[f].z : 0.f, live ? v[f].w : 0.f};
+            const float w[4] = {live ? v[f][0] : 0.f, live ? v[f][1] : 0.f, live ? v[f][2] : 0.f, live ? v[f][3] : 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xv[4 * f + e] = w[e];
@@ -291,6 +307,10 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
                 *reinterpret_cast<uint4*>(XS + k * WS_XS_TERM + jl * WS_XS_TILE + (4 * h + g4) * 256 + col * 16) =
                     uint4{t[h][0][k], t[h][1][k], t[h][2][k], t[h][3][k]};
     };
+    PR[tid] = pr_v;
+    float us_s[4];                                  // (readfirstlane: uniform values into scalar registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) us_s[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, us_v[i])));
     if (have_tok && (mlp_only || wave < 6)) write_split(wave);
     wb_sync();
     WB_STAMP(1);
