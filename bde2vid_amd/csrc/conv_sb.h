@@ -145,6 +145,14 @@ static inline long split_bf16_bytes(long N, int C, long HW, int terms = 3) { ret
 // a.in = SB16 activations (as float*), a.wpk = split packed weights; group / frame strides of `in` in BYTES / 4 (floats).
 // DB: two halo buffers in LDS, the next chunk's DMA in flight during the MFMAs of the current one -- for the small launches
 // of the recurrent step, where a CU holds one or two workgroups and nobody else covers the staging.
+#ifndef CONV_SB_STAGGER
+#define CONV_SB_STAGGER 0
+#endif
+// timing experiments only (results are wrong): 1 = no weight-fragment loads in the tap loop, 2 = pixel fragments read at the first tap
+// of a chunk only, 4 = halo tiles staged for the first chunk only
+#ifndef CONV_SB_DBG
+#define CONV_SB_DBG 0
+#endif
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2, TAPS = KS * KS;
@@ -156,6 +164,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     const int hl = lane >> 5;
     int bx, by, z;
     conv_block_coords(a.xcd_remap, bx, by, z);
+    if (CONV_SB_STAGGER > 0 && !DB) {
+        // The workgroups of a launch start together and, without a second halo buffer, stop together at every chunk boundary
+        // (barrier, DMA, wait, barrier).  The dispatch rounds -- one workgroup per CU each -- start a fraction of a chunk apart so
+        // that the two or three workgroups of a CU cover each other's staging.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned round = (lin >> 8) % 3u;
+        for (unsigned i = 0; i < round; ++i) __builtin_amdgcn_s_sleep(CONV_SB_STAGGER);       // CONV_SB_STAGGER x 64 cycles per round
+    }
     const int g = z / a.N, n = z - g * a.N;
     const int HW = a.Ho * a.Wo;
     int p_end, iy0, ix0, R, IW;
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     for (int c16 = 0; c16 < C16; ++c16) {
         if (!DB) {
             __syncthreads();                               // every wave is done with the previous chunk's tile
-            stage(c16);
+            if (!(CONV_SB_DBG & 4) || c16 == 0) stage(c16);
         }
         const unsigned char* tile = sb_lds + (DB ? (c16 & 1) * tile_bytes : 0);
         if (DB) {
@@ -299,11 +315,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (DB && c16 + 1 < C16) stage(c16 + 1);            // (every wave left the other buffer before that barrier)
+        sb8 bfr[NT][TERMS];
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int cur = tap % RING, nxt = (tap + PF) % RING;
             {
                 const long sp = min(c16 * TAPS + tap + PF, S - 1);
+                if (!(CONV_SB_DBG & 1))
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             // every tap, an L2 round trip in front of each six MFMAs.
             __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / KS, kx = tap - ky * KS;
-            sb8 bfr[NT][TERMS];
+            if (!(CONV_SB_DBG & 2) || tap == 0)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll

@@ -736,46 +736,54 @@ __global__ __launch_bounds__(1024) void winblock_sb_kernel(const WinArgs a) {
         }
         if (TERMS == 2) sb_guard_flush(gm, a.ovf);
     }
+    // fc2's remaining fragments (k-steps 2..7 of this wave's row tile) and the frame's residual (merged[t]) are requested HERE, in
+    // front of the barrier that ends fc1: requested round by round inside the fc2 loop the scheduler sank every load to its use
+    // (ISA of round 4: load, s_waitcnt vmcnt(1), MFMA -- three dependent round trips in a phase of sixteen MFMAs), and the residual
+    // was a round trip of its own in front of the stores.
+    sb8 wr[3][2][TERMS];
+#pragma unroll
+    for (int kp = 1; kp < 4; ++kp)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int k = 0; k < TERMS; ++k) wr[kp - 1][ks][k] = w2[((kp * 2 + ks) * TERMS + k) * 64];
+    const int pix_o = PIX[(wave >> 2) * 16 + col2];
+    f32x4 ad_v = {0.f, 0.f, 0.f, 0.f};
+    {
+        typedef const __attribute__((address_space(1))) f32x4 gf4;
+        const bool has = a.addres != nullptr && pix_o >= 0;
+        const float* adp = has ? a.addres + b * a.addres_bs + (long)pix_o * WB_C + (wave & 3) * 16 + g42 * 4 : a.bfc2;
+        ad_v = *(gf4*)reinterpret_cast<const f32x4*>(adp);
+        if (!has) ad_v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
     wb_sync();
     { const int lane = lane2; WB_STAMP(5); }
 
     // ---- x2 = x1 + fc2(hidden) (+ merged[t]): 4 row tiles x 4 token tiles, K = 256 = 8 k-steps ----------------------
     {
         const int rt = wave & 3, i = wave >> 2;
-        sb8 wb[2][TERMS];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) {                // two k-steps per round, the next round's fragments in flight
-            if (kp + 1 < 4) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int k = 0; k < TERMS; ++k) {
-                        const sb8 v = w2[(((kp + 1) * 2 + ks) * TERMS + k) * 64];
-                        if (kp & 1) wa[ks][k] = v; else wb[ks][k] = v;
-                    }
-            }
+        for (int kp = 0; kp < 4; ++kp) {                // two k-steps per round
             sb8 b0[TERMS], b1[TERMS];
             load_b2(HS, WS_HID_TERM, WS_HID_TILE, i, 2 * kp, b0);
             load_b2(HS, WS_HID_TERM, WS_HID_TILE, i, 2 * kp + 1, b1);
-            if (kp & 1) {
-                acc = sb_mma16<TERMS>(wb[0], b0, acc);
-                acc = sb_mma16<TERMS>(wb[1], b1, acc);
-            } else {
+            if (kp == 0) {
                 acc = sb_mma16<TERMS>(wa[0], b0, acc);
                 acc = sb_mma16<TERMS>(wa[1], b1, acc);
+            } else {
+                acc = sb_mma16<TERMS>(wr[kp - 1][0], b0, acc);
+                acc = sb_mma16<TERMS>(wr[kp - 1][1], b1, acc);
             }
         }
-        const int pix = PIX[i * 16 + col2];
+        const int pix = pix_o;
         if (pix >= 0) {
             const int row0 = rt * 16 + g42 * 4;
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = XT[(i * WB_C + row0 + r) * 16 + col2] + WS_US(acc[r], 3) + pbfc2[row0 + r];
-            if (a.addres) {
-                const float4 ad = *reinterpret_cast<const float4*>(a.addres + b * a.addres_bs + (long)pix * WB_C + row0);
-                y[0] += ad.x; y[1] += ad.y; y[2] += ad.z; y[3] += ad.w;
-            }
+            if (a.addres) { y[0] += ad_v[0]; y[1] += ad_v[1]; y[2] += ad_v[2]; y[3] += ad_v[3]; }
             *reinterpret_cast<float4*>(a.out + b * a.out_bs + (long)pix * WB_C + row0) = float4{y[0], y[1], y[2], y[3]};
             if (a.out_nchw) {
                 float* ob = a.out_nchw + b * a.out_bs + pix;
