@@ -85,6 +85,10 @@ struct LstmSbArgs {
 #ifndef LSB_STAGGER
 #define LSB_STAGGER 0
 #endif
+// timing experiments only (results are wrong): 1 = no weight-fragment loads in the tap loop, 2 = pixel fragments of the first unit only
+#ifndef LSB_DBG
+#define LSB_DBG 0
+#endif
 #define LSB_STAMP(i)                                                                              \
     do {                                                                                          \
         if (a.stamps && !a.stamp_mode && lane == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0)       \
@@ -308,15 +312,15 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
 #pragma unroll
             for (int u = 0; u < TAPS * NT; ++u) {
                 const int tap = u / NT, t = u - tap * NT;
-                if (t == 0) {
+                if (t == 0 && !(LSB_DBG & 1)) {
                     const int nxt = (tap + PF) % RING;
                     const long sp = min(s * TAPS + tap + PF, S - 1);
 #pragma unroll
                     for (int k = 0; k < TERMS; ++k) af[nxt][k] = wfr[(sp * TERMS + k) * 64];
                 }
-                if (u + 1 < TAPS * NT) read_unit(u + 1, bb[(u + 1) & 1]);
+                if (u + 1 < TAPS * NT && !(LSB_DBG & 2)) read_unit(u + 1, bb[(u + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t] = sb_mma32<TERMS>(af[tap % RING], bb[u & 1], acc[t]);
+                acc[t] = sb_mma32<TERMS>(af[tap % RING], bb[(LSB_DBG & 2) ? 0 : (u & 1)], acc[t]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
