@@ -118,6 +118,9 @@ struct WideCoreArgs {
             a.stamps[(blockIdx.x * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
     } while (0)
 
+#ifndef WC_XCD_REMAP
+#define WC_XCD_REMAP 1
+#endif
 constexpr int WC_WL_BYTES = 3 * 8 * 2 * 1024;
 constexpr int WC_LDS_BYTES = WC_WL_BYTES + (2 * 10 * 16 * 16 + 2 * 48) * 4;      // 68.5 KB: two workgroups per CU
 
@@ -133,7 +136,23 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, col = lane & 15;
-    const int win = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    // Workgroup -> (window, head, batch), head-major inside each XCD.  The dispatcher deals consecutive workgroups round-robin to the 8
+    // XCDs: in grid order every XCD sees every head and pulls all 786 KB of a block's q|k|v fragments into its L2 in every launch --
+    // the level's 19 MB of weights cycle through the 4 MB L2s once per frame, so that is a fill from the Infinity Cache each time.
+    // With a contiguous range of the (batch, head, window) order per XCD, an XCD holds two heads: an eighth of the fragments.
+    int win, head, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        unsigned L = lin;
+        if (WC_XCD_REMAP) {
+            const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
+            L = xcd * q + min(xcd, rem) + (lin >> 3);
+        }
+        win = (int)(L % gx);
+        head = (int)((L / gx) % gy);
+        b = (int)(L / (gx * gy));
+    }
     const int wi = win / a.nWw, wj = win - wi * a.nWw;
     const int step = a.dilated ? 2 : 1;
     const int c0 = head * HD;

@@ -74,6 +74,9 @@ __device__ __forceinline__ f32x4 ld_sc1_f4(const float* p) {
 #ifndef WM_PD
 #define WM_PD 3
 #endif
+#ifndef WM_XCD_REMAP
+#define WM_XCD_REMAP 1
+#endif
 // C = 256 channels, hidden = 1024.  grid (token tiles, 4 quarters of the hidden rows, B), 256 threads.
 __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     constexpr int NKS = 8;                 // k-steps of 32 per phase (K = 256 per workgroup in all three GEMMs)
@@ -88,7 +91,21 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g4 = lane >> 4, col = lane & 15;
-    const int tile = blockIdx.x, quarter = blockIdx.y, b = blockIdx.z;
+    // Workgroup -> (token tile, quarter, batch), quarter-major inside each XCD (see wide_core.h): an XCD then streams proj and ONE
+    // quarter of fc1 / fc2 (768 KB) through its L2 instead of all four (2.3 MB).
+    int tile, quarter, b;
+    {
+        const unsigned gx = gridDim.x, total = gx * 4u * gridDim.z;
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + 4u * blockIdx.z);
+        unsigned L = lin;
+        if (WM_XCD_REMAP) {
+            const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
+            L = xcd * q + min(xcd, rem) + (lin >> 3);
+        }
+        tile = (int)(L % gx);
+        quarter = (int)((L / gx) & 3u);
+        b = (int)(L / (gx * 4u));
+    }
     const int tok = tile * 16 + col;
     WM_STAMP(0);
     // The accumulator scales of the three GEMMs (split.h) are requested FIRST and turned into scalars behind the first fragment
