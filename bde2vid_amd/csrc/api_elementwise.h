@@ -183,8 +183,104 @@ __global__ __launch_bounds__(256) void upsample2x_sum_split_kernel(const float* 
         *reinterpret_cast<uint4*>(d + kk * 16) = v;
     }
 }
+// The same image, a thread = the 2 x 2 output pixels of one source pixel (k, j) x half a chunk: their bilinear taps are the 3 x 3
+// source neighbourhood (rows k - 1 .. k + 1, columns j - 1 .. j + 1, clamped), nine loads per tensor and channel for four outputs
+// instead of sixteen, and a wave's loads are 64 CONSECUTIVE source floats of a plane row (the per-output-pixel kernel reads every
+// source float twice over two lanes).  Same expression per output as upsample2x_sum_kernel / upsample2x_sum_split_kernel (bit-identical).
+// grid (ceil(Hs Ws / 128), C/16 chunks, N), 256 threads = 128 source pixels x 2 halves.
+template <int TERMS>
+__global__ __launch_bounds__(256) void upsample2x_sum_split_quad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                        unsigned short* __restrict__ out, int C, int Hs, int Ws,
+                                                                        unsigned* ovf) {
+    const int Wo = 2 * Ws;
+    const long HWo = 4L * Hs * Ws, HWs = (long)Hs * Ws;
+    const int half = threadIdx.x >> 7, sl = threadIdx.x & 127;
+    const bool live = (long)blockIdx.x * 128 + sl < HWs;
+    const long sp = min((long)blockIdx.x * 128 + sl, HWs - 1);
+    const int c16 = blockIdx.y, C16 = gridDim.y;
+    const long n = blockIdx.z;
+    const int k = (int)(sp / Ws), j = (int)(sp - (long)k * Ws);
+    const int km = max(k - 1, 0), kp = min(k + 1, Hs - 1), jm = max(j - 1, 0), jp = min(j + 1, Ws - 1);
+    // output (2k + dy, 2j + dx): rows (ya, yb) = dy ? (k, kp) : (km, k), weight of yb = dy ? 0.25 : 0.75 (1 where ya == yb); columns alike
+    const float wyb0 = km == k ? 1.f : 0.75f, wyb1 = k == kp ? 1.f : 0.25f;
+    const float wxb0 = jm == j ? 1.f : 0.75f, wxb1 = j == jp ? 1.f : 0.25f;
+    const float wya0 = 1.f - wyb0, wya1 = 1.f - wyb1, wxa0 = 1.f - wxb0, wxa1 = 1.f - wxb1;
+    const int r0 = km * Ws, r1 = k * Ws, r2 = kp * Ws;
+    unsigned short t[4][8][TERMS];
+    float gm = 0.f;                                        // range guard of the two-term format (split.h)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = c16 * 16 + half * 8 + q;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+            const float* pa = a + (n * C + c) * HWs;
+            float v[3][3] = {{pa[r0 + jm], pa[r0 + j], pa[r0 + jp]}, {pa[r1 + jm], pa[r1 + j], pa[r1 + jp]}, {pa[r2 + jm], pa[r2 + j], pa[r2 + jp]}};
+            if (b) {
+                const float* pb = b + (n * C + c) * HWs;
+                v[0][0] += pb[r0 + jm]; v[0][1] += pb[r0 + j]; v[0][2] += pb[r0 + jp];
+                v[1][0] += pb[r1 + jm]; v[1][1] += pb[r1 + j]; v[1][2] += pb[r1 + jp];
+                v[2][0] += pb[r2 + jm]; v[2][1] += pb[r2 + j]; v[2][2] += pb[r2 + jp];
+            }
+            // o = wya (wxa vaa + wxb vab) + wyb (wxa vba + wxb vbb)
+            o[0] = wya0 * (wxa0 * v[0][0] + wxb0 * v[0][1]) + wyb0 * (wxa0 * v[1][0] + wxb0 * v[1][1]);
+            o[1] = wya0 * (wxa1 * v[0][1] + wxb1 * v[0][2]) + wyb0 * (wxa1 * v[1][1] + wxb1 * v[1][2]);
+            o[2] = wya1 * (wxa0 * v[1][0] + wxb0 * v[1][1]) + wyb1 * (wxa0 * v[2][0] + wxb0 * v[2][1]);
+            o[3] = wya1 * (wxa1 * v[1][1] + wxb1 * v[1][2]) + wyb1 * (wxa1 * v[2][1] + wxb1 * v[2][2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (TERMS == 2) gm = sb_guard_max(gm, o[i]);
+            sb_split_dev<TERMS>(o[i], t[i][q]);
+        }
+    }
+    if (TERMS == 2) sb_guard_flush(gm, ovf);
+    // The 16-byte pieces go out through LDS: written by their producers (a pixel's pieces of one half sit 32 bytes apart, the
+    // pixels of consecutive lanes 128 bytes apart: stored directly, a wave's store instruction is 64 partial writes into 64
+    // different lines), read back piece-major, so that a wave stores 1 KiB of consecutive bytes per instruction.
+    constexpr int PB = 32 * TERMS, PITCH = PB + 16;       // bytes of a pixel's chunk image; its pitch in LDS (bank spread)
+    __shared__ __align__(16) unsigned char stg[2 * 256 * (32 * TERMS + 16)];
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned char* d = stg + ((i >> 1) * 256 + 2 * sl + (i & 1)) * PITCH + half * 16;
+#pragma unroll
+            for (int kk = 0; kk < TERMS; ++kk) {
+                uint4 v;
+                v.x = t[i][0][kk] | ((unsigned)t[i][1][kk] << 16);
+                v.y = t[i][2][kk] | ((unsigned)t[i][3][kk] << 16);
+                v.z = t[i][4][kk] | ((unsigned)t[i][5][kk] << 16);
+                v.w = t[i][6][kk] | ((unsigned)t[i][7][kk] << 16);
+                *reinterpret_cast<uint4*>(d + kk * 32) = v;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int PPP = 2 * TERMS;                        // 16-byte pieces per pixel
+    const long sp0 = (long)blockIdx.x * 128;
+    const int npix = (int)min(128L, HWs - sp0);           // source pixels of this workgroup
+    unsigned short* ob = out + ((n * C16 + c16) * HWo) * TERMS * 16;
+    for (int it = threadIdx.x; it < 2 * 2 * npix * PPP; it += 256) {
+        const int q = it % PPP, px = it / PPP;            // px = dy * (2 npix) + 2 sl + dx
+        const int dy = px / (2 * npix), xx = px - dy * 2 * npix, sl2 = xx >> 1, dx = xx & 1;
+        const long spx = sp0 + sl2;
+        const int k2 = (int)(spx / Ws), j2 = (int)(spx - (long)k2 * Ws);
+        const long p = (long)(2 * k2 + dy) * Wo + 2 * j2 + dx;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + (dy * 256 + xx) * PITCH + q * 16);
+        *reinterpret_cast<uint4*>(ob + p * TERMS * 16 + q * 8) = v;
+    }
+}
+#ifndef BDE_UPS_QUAD
+#define BDE_UPS_QUAD 1
+#endif
 static int upsample2x_sum_split(const float* a, const float* b, void* out_sb, int N, int C, int Hs, int Ws, int terms, unsigned* ovf,
                                 hipStream_t s) {
+    if (BDE_UPS_QUAD) {
+        const dim3 gq((unsigned)cdivl((long)Hs * Ws, 128), cdiv(C, 16), (unsigned)N);
+        if (terms == 2) hipLaunchKernelGGL(upsample2x_sum_split_quad_kernel<2>, gq, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws, ovf);
+        else hipLaunchKernelGGL(upsample2x_sum_split_quad_kernel<3>, gq, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws, ovf);
+        BDE_HIP(hipGetLastError());
+        return BDE_OK;
+    }
     const dim3 grid((unsigned)cdivl(4L * Hs * Ws, 128), cdiv(C, 16), (unsigned)N);
     if (terms == 2) hipLaunchKernelGGL(upsample2x_sum_split_kernel<2>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws, ovf);
     else hipLaunchKernelGGL(upsample2x_sum_split_kernel<3>, grid, dim3(256), 0, s, a, b, (unsigned short*)out_sb, C, Hs, Ws, ovf);
