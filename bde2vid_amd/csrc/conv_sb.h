@@ -31,11 +31,11 @@ namespace bde {
 template <int TERMS>
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, long HW,
                                                          unsigned* ovf) {
-    const int half = threadIdx.x >> 7;
-    const long p = (long)blockIdx.x * 128 + (threadIdx.x & 127);
+    const int half = threadIdx.x >> 7, pl = threadIdx.x & 127;
+    const long p0 = (long)blockIdx.x * 128;
+    const long p = min(p0 + pl, HW - 1);
     const int c16 = blockIdx.y;
     const long n = blockIdx.z;
-    if (p >= HW) return;
     const int C16 = gridDim.y;
     unsigned short t[8][TERMS];
     float gm = 0.f;                                        // range guard of the two-term format (split.h)
@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         sb_split_dev<TERMS>(x, t[j]);
     }
     if (TERMS == 2) sb_guard_flush(gm, ovf);
-    unsigned short* o = out + (((n * C16 + c16) * HW + p) * TERMS) * 16 + half * 8;
+    // through LDS, so that a wave stores 1 KiB of consecutive bytes per instruction (stored by their producers, a wave's 16-byte
+    // pieces are 64 partial writes into 64 different lines: api_elementwise.h, upsample2x_sum_split_quad_kernel)
+    constexpr int PB = 32 * TERMS, PITCH = PB + 16;
+    __shared__ __align__(16) unsigned char stg[128 * (32 * TERMS + 16)];
 #pragma unroll
     for (int k = 0; k < TERMS; ++k) {
         uint4 v;
@@ -55,7 +58,15 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         v.y = t[2][k] | ((unsigned)t[3][k] << 16);
         v.z = t[4][k] | ((unsigned)t[5][k] << 16);
         v.w = t[6][k] | ((unsigned)t[7][k] << 16);
-        *reinterpret_cast<uint4*>(o + k * 16) = v;
+        *reinterpret_cast<uint4*>(stg + pl * PITCH + k * 32 + half * 16) = v;
+    }
+    __syncthreads();
+    const int npix = (int)min(128L, HW - p0);
+    unsigned char* ob = reinterpret_cast<unsigned char*>(out + (((n * C16 + c16) * HW + p0) * TERMS) * 16);
+    constexpr int PPP = 2 * TERMS;                         // 16-byte pieces per pixel
+    for (int it = threadIdx.x; it < npix * PPP; it += 256) {
+        const int q = it % PPP, px = it / PPP;
+        *reinterpret_cast<uint4*>(ob + (long)px * PB + q * 16) = *reinterpret_cast<const uint4*>(stg + px * PITCH + q * 16);
     }
 }
 int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, unsigned* ovf, hipStream_t s) {
