@@ -84,6 +84,7 @@ struct ConvArgs {
     int sb_terms;
     const float* acc_scale;
     unsigned* sb_ovf;            // range guard of the two-term format (split.h): the forward's overflow word, written by sb_out stores
+    int sb_stage_ok;             // conv_sb.h: the workgroup's LDS holds its SB16 output tile (staged, piece-major stores); set by the launcher
     int xcd_remap;               // conv_sb.h: workgroup order that keeps neighbouring tiles in one XCD's L2
     // one sweep direction per GPU (bde_split_*): the launch covers `groups` of the layer's groups, but every launch-shape
     // choice is made as if all `decide_groups` were present, so each direction computes exactly what the joint launch computes

@@ -159,6 +159,9 @@ static inline long split_bf16_bytes(long N, int C, long HW, int terms = 3) { ret
 #ifndef CONV_SB_STAGGER
 #define CONV_SB_STAGGER 0
 #endif
+#ifndef CONV_SB_STAGED_EPI
+#define CONV_SB_STAGED_EPI 1
+#endif
 // timing experiments only (results are wrong): 1 = no weight-fragment loads in the tap loop, 2 = pixel fragments read at the first tap
 // of a chunk only, 4 = halo tiles staged for the first chunk only
 #ifndef CONV_SB_DBG
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
     const int HW = a.Ho * a.Wo;
     int p_end, iy0, ix0, R, IW;
     int boff[NT], pix[NT];
+    int ep_p0 = 0, ep_y0 = 0, ep_x0 = 0;                    // the tile's first pixel / corner, for the staged SB16 epilogue
     if (a.tile_cols > 0) {
         // 2-D pixel tile of tile_rows x tile_cols output pixels (= BN): the halo is a small rectangle instead of KS whole
         // row segments.  Pixel q of the tile = (q / tile_cols, q % tile_cols); lanes outside the image compute on halo zeros
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
         const int tiles_x = (a.Wo + TC - 1) / TC;
         const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
         const int y0 = ty * TR, x0 = tx * TC;
+        ep_y0 = y0; ep_x0 = x0;
         p_end = HW;
         iy0 = y0 * STRIDE - PAD;
         ix0 = x0 * STRIDE - PAD;
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             p0 = bx * BN;
             p_end = min(p0 + BN, HW);
         }
+        ep_p0 = p0;
         const int p_last = p_end - 1;
         const int y_first = p0 / a.Wo, y_last = p_last / a.Wo;
         const bool one_row = (y_first == y_last);
@@ -365,6 +371,72 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) fin[m][t][rr] = TERMS == 2 ? acc[m][t][rr] * unscale : acc[m][t][rr];
+    if (CONV_SB_STAGED_EPI && a.sb_out != nullptr && a.pred_out == nullptr && a.sb_stage_ok) {
+        // ---- SB16 output through LDS ------------------------------------------------------------------------------------------------
+        // generic_epilogue stores a lane's four consecutive channels of one term: 8 bytes, 64 bytes apart from lane to lane -- a wave's
+        // store instruction is 64 partial writes into 32 different lines, eight such instructions per line (11 M write requests for
+        // encoder 0's 90 MB).  The halo tiles are dead: the workgroup's output tile is assembled there in the image's own layout
+        // ([chunk][pixel][term][16 channels]) and leaves as 16-byte pieces, consecutive lanes = consecutive bytes.
+        constexpr int LC = WM * MT * 2, NTHR = 64 * WM * WN;  // 16-channel chunks of the workgroup's rows
+        constexpr int PB = 32 * TERMS, PITCH = PB + 16, PPP = 2 * TERMS;
+        __syncthreads();                                   // every wave is done with the last chunk's tile
+        unsigned char* stg = sb_lds;
+        const float* biasg = a.bias + g * a.bias_gs;
+        float gm = 0.f;
+        if (cot0 * 32 < a.Cout) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co0 = (cot0 + m) * 32 + 8 * q + 4 * hl;          // = acc_row(4 q, lane): four consecutive channels
+                    float b4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b4[i] = biasg[min(co0 + i, a.Cout - 1)];
+                    const int lc = (wm * MT + m) * 2 + (q >> 1), c16 = 8 * (q & 1) + 4 * hl;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        float v4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v4[i] = act_apply(fin[m][t][4 * q + i] + b4[i], a.act);
+                        unsigned char* d = stg + (lc * BN + (wn * NT + t) * 32 + (lane & 31)) * PITCH + c16 * 2;
+                        if constexpr (TERMS == 2) {
+                            uint2 hi, lo;
+                            gm = sb_guard_max2(sb_guard_max2(gm, v4[0], v4[1]), v4[2], v4[3]);
+                            split2_quad(v4, hi, lo);
+                            *reinterpret_cast<uint2*>(d) = hi;
+                            *reinterpret_cast<uint2*>(d + 32) = lo;
+                        } else {
+                            uint2 hi, mid, lo;
+                            split3_quad(v4, hi, mid, lo);
+                            *reinterpret_cast<uint2*>(d) = hi;
+                            *reinterpret_cast<uint2*>(d + 32) = mid;
+                            *reinterpret_cast<uint2*>(d + 64) = lo;
+                        }
+                    }
+                }
+        }
+        if (TERMS == 2) sb_guard_flush(gm, a.sb_ovf);
+        __syncthreads();
+        unsigned char* sbb = reinterpret_cast<unsigned char*>(a.sb_out + g * a.sb_out_gs + n * a.sb_out_ns);
+        const int chunk0 = by * LC;
+        const int TC = a.tile_cols;
+        for (int it = tid; it < LC * BN * PPP; it += NTHR) {
+            const int q = it % PPP, r = it / PPP;
+            const int pw = r % BN, lc = r / BN;
+            int p;
+            if (TC > 0) {
+                const int qy = pw / TC, qx = pw - qy * TC;
+                const int y = ep_y0 + qy, x = ep_x0 + qx;
+                p = (y < a.Ho && x < a.Wo) ? y * a.Wo + x : HW;
+            } else {
+                p = ep_p0 + pw;
+            }
+            if (p >= p_end || (chunk0 + lc) * 16 >= a.Cout) continue;
+            *reinterpret_cast<uint4*>(sbb + ((long)(chunk0 + lc) * HW + p) * PB + q * 16) =
+                *reinterpret_cast<const uint4*>(stg + (lc * BN + pw) * PITCH + q * 16);
+        }
+        return;
+    }
     float mu[NT], rstd[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) mu[t] = rstd[t] = 0.f;
@@ -458,7 +530,9 @@ static int conv_sb_launch_t(const ConvArgs& a, int G, hipStream_t stream, long h
     dim3 grid(a.row_tiles > 0 ? a.Ho * a.row_tiles : cdiv(a.Ho * a.Wo, BN), cdiv(a.Cout, WM * MT * 32), G * a.N);
     if (a.tile_cols > 0) grid.x = cdiv(a.Wo, a.tile_cols) * cdiv(a.Ho, BN / a.tile_cols);
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return BDE_OK;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, a);
+    ConvArgs b = a;
+    b.sb_stage_ok = (size_t)(WM * MT * 2) * BN * (32 * TERMS + 16) <= lds ? 1 : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, b);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
