@@ -439,6 +439,146 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
         *reinterpret_cast<float4*>(a.out_tok + b * a.out_bs + (long)tok * a.M + row0) = float4{v[0], v[1], v[2], v[3]};
     }
 }
+// The T-batched form of the same GEMM (the K|V rows of the unrefined frames: 11 040 tokens x 3 072 rows at config A).  In
+// tokgemm_sb_kernel a workgroup is 4 token tiles x 4 row tiles: the tokens of a tile are read and split by the 48 workgroups that
+// share them, and a workgroup lives for ~100 MFMAs per wave behind a prologue of its own.  Here a wave splits its token tile ONCE
+// (sixteen B fragments, 64 registers), computes its LayerNorm statistics once and then walks RGN groups of four row tiles: one stream of
+// weight fragments (the four waves of a workgroup ask for the same ones: L1), MFMAs and 16-byte stores.  The sum over k runs in the
+// same order as in tokgemm_sb_kernel: identical results.  K = 256.
+#ifndef TOKGEMM_SB_RGN
+#define TOKGEMM_SB_RGN 12
+#endif
+#ifndef TOKGEMM_SB_PD
+#define TOKGEMM_SB_PD 3
+#endif
+#ifndef TOKGEMM_SB_MT
+#define TOKGEMM_SB_MT 4
+#endif
+#ifndef TOKGEMM_SB_OCC
+#define TOKGEMM_SB_OCC 1
+#endif
+template <int RGN, int MT>
+__global__ __launch_bounds__(256, TOKGEMM_SB_OCC) void tokgemm_sb_rows_kernel(const TokGemmArgs a) {
+    constexpr int KS = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g4 = lane >> 4, col = lane & 15;
+    const int b = blockIdx.z;
+    const int ngk = a.K >> 4, ngm = a.M >> 4;
+    const int tile = min((int)blockIdx.x * 4 + wave, a.ntile - 1);          // (a wave past the last tile repeats it and stores nothing)
+    const bool tile_live = (int)blockIdx.x * 4 + wave < a.ntile;
+    const int rtg0 = blockIdx.y * MT * RGN;
+    const float unscale_v = a.w_unscale[0];
+    const wf4* xp = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)tile * ngk) * 64 + lane;
+    wf4 xv[KS][2];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        xv[k][0] = xp[(long)(2 * k) * 64];
+        xv[k][1] = xp[(long)(2 * k + 1) * 64];
+    }
+    const sb8* wbase = reinterpret_cast<const sb8*>(a.wS) + lane;
+    auto wfrag = [&](int rt, int k, int t) { return wbase[(((long)min(rt, ngm - 1) * KS + k) * 2 + t) * 64]; };
+    const float* lsum = a.lnsum ? a.lnsum : a.bias;        // (pointer select: no load under a branch)
+    // weight fragments run PD k-steps ahead of the MFMAs in a ring of PD + 1 register sets (8 steps per group: a step's ring position is
+    // a compile-time constant); one wave per SIMD at this register count, so the distance has to cover an L2 round trip by itself
+    constexpr int PD = TOKGEMM_SB_PD, RING = PD + 1;
+    static_assert(KS % RING == 0, "ring position of a k-step must not depend on the group");
+    sb8 av[RING][MT][2];
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[j][m][t] = wfrag(rtg0 + m, j, t);
+    __builtin_amdgcn_sched_barrier(0);
+    // the token tile: statistics and split, once
+    float s1 = 0.f, s2 = 0.f, gm = 0.f;
+    sb8 bfr[KS][2];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const wf4 x0 = xv[k][0], x1 = xv[k][1];
+        s1 += ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+        s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+              ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
+        unsigned t[4][2];
+        ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
+        ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
+        ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
+        ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bfr[k][q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+    }
+    sb_guard_flush(gm, a.ovf);
+    float mu = 0.f, rstd = 1.f;
+    if (a.lnsum) {
+        float u = s1, v = s2;
+        u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+        u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+        const float mean = u / (float)a.K;
+        const float var = fmaxf(v / (float)a.K - mean * mean, 0.f);
+        mu = mean;
+        rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+    }
+    const float unscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, unscale_v)));
+    constexpr int SP = MT * 16 + 4;                       // floats per token in the staging tile (+ 4: bank spread)
+    __shared__ __align__(16) float stg_all[4][16 * (MT * 16 + 4)];
+    float* stg = stg_all[wave];
+#pragma unroll 1
+    for (int rg = 0; rg < RGN; ++rg) {
+        const int rt0 = rtg0 + rg * MT;
+        if (rt0 >= ngm) break;
+        float bb[MT][4], ss[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row0 = min(rt0 + m, ngm - 1) * 16 + g4 * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bb[m][r] = a.bias[row0 + r];
+                ss[m][r] = lsum[row0 + r];
+            }
+        }
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            // the next k-step's fragments (the next group's first ones behind the last step): requested here, used a step later
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    av[(k + PD) % RING][m][t] = k + PD < KS ? wfrag(rt0 + m, k + PD, t) : wfrag(rt0 + MT + m, k + PD - KS, t);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = sb_mma16<2>(av[k % RING][m], bfr[k], acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the group's 16 tokens x (MT x 16) rows go out through the wave's corner of LDS: a lane holds four rows of ONE token, so stored
+        // directly an instruction is sixteen 64-byte halves of sixteen different lines (the launch then FETCHES 240 MB to fill the
+        // lines it half-writes: rocprofv3 FETCH_SIZE); read back token-major, sixteen lanes write the 16 MT rows x 4 bytes of a token.
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = acc[m][r] * unscale;
+                if (a.lnsum) y = rstd * (y - mu * ss[m][r]);
+                v[r] = act_apply(y + bb[m][r], a.act);
+            }
+            *reinterpret_cast<f32x4*>(stg + col * SP + m * 16 + g4 * 4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        constexpr int LPT = MT * 4;                       // lanes (16-byte pieces) per token
+#pragma unroll
+        for (int j = 0; j < 16 * LPT / 64; ++j) {
+            const int tk = (j * 64 + lane) / LPT, pc = (j * 64 + lane) % LPT;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + tk * SP + pc * 4);
+            const int tokk = tile * 16 + tk, rt = rt0 + (pc >> 2);
+            if (tile_live && tokk < a.HW && rt < ngm)
+                *reinterpret_cast<f32x4*>(a.out_tok + b * a.out_bs + (long)tokk * a.M + (long)rt0 * 16 + pc * 4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 static bool tokgemm_sb_fits(const TokGemmArgs& a) {
     return a.wS != nullptr && a.out_tok != nullptr && a.res == nullptr && a.addres == nullptr && a.K % 32 == 0 && a.M % 16 == 0 && a.mask_w == 0;
 }
@@ -448,6 +588,13 @@ static int tokgemm_sb_launch(const TokGemmArgs& a, int B, hipStream_t s) {
     // (eight row tiles per wave would halve the split work per MFMA on the T-batched launch, but need 239 + 32 registers: one wave
     //  per SIMD; four row tiles: 212, two waves)
     (void)tiles;
+    if (TOKGEMM_SB_RGN > 0 && a.K == 256 && (long)a.ntile * B >= 256 && ngm >= TOKGEMM_SB_MT * TOKGEMM_SB_RGN) {
+        // the T-batched launch: a wave keeps its split token tile and walks TOKGEMM_SB_RGN groups of TOKGEMM_SB_MT row tiles
+        hipLaunchKernelGGL((tokgemm_sb_rows_kernel<TOKGEMM_SB_RGN, TOKGEMM_SB_MT>), dim3(cdiv(a.ntile, 4), cdiv(ngm, TOKGEMM_SB_MT * TOKGEMM_SB_RGN), B),
+                           dim3(256), 0, s, a);
+        BDE_HIP(hipGetLastError());
+        return BDE_OK;
+    }
     hipLaunchKernelGGL(tokgemm_sb_kernel<4>, dim3(cdiv(a.ntile, 4), cdiv(ngm, 4), B), dim3(256), 0, s, a);
     BDE_HIP(hipGetLastError());
     return BDE_OK;
