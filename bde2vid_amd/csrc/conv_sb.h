@@ -159,6 +159,9 @@ static inline long split_bf16_bytes(long N, int C, long HW, int terms = 3) { ret
 #ifndef CONV_SB_STAGGER
 #define CONV_SB_STAGGER 0
 #endif
+#ifndef CONV_SB_T32_NT
+#define CONV_SB_T32_NT 2
+#endif
 #ifndef CONV_SB_STAGED_EPI
 #define CONV_SB_STAGED_EPI 1
 #endif
@@ -599,7 +602,13 @@ static int conv_sb_launch_ks(const ConvArgs& a, int G, hipStream_t stream, bool*
     if (shape == SB_128x64) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 4, 1, TERMS>(a, G, stream, launched);
     if constexpr (KS == 5 && STRIDE == 1) {
         if (shape == SB_64x128) return conv_sb_launch_shape<KS, STRIDE, 1, 2, 2, 2, TERMS>(a, G, stream, launched);
-        if (shape == SB_32x256T) return conv_sb_launch_2d<KS, STRIDE, 1, 2, 1, 4, TERMS>(a, G, stream, launched);
+        // (CONV_SB_T32_NT = 4: 128 pixels per wave, a 512-pixel tile -- the four waves of this shape read the SAME weight fragments, each
+        //  through the vector memory path: twice the pixels per wave halve those bytes per MFMA; needs >= 4 workgroups per CU of such tiles)
+        if (shape == SB_32x256T) {
+            if (CONV_SB_T32_NT == 4 && (long)cdiv(a.Ho * a.Wo, 512) * G * a.N >= 4 * 256)
+                return conv_sb_launch_2d<KS, STRIDE, 1, 4, 1, 4, TERMS>(a, G, stream, launched);
+            return conv_sb_launch_2d<KS, STRIDE, 1, 2, 1, 4, TERMS>(a, G, stream, launched);
+        }
     }
     if constexpr (KS == 5 && STRIDE == 2)
         if (shape == SB_64x128T) return conv_sb_launch_2d<KS, STRIDE, 1, 2, 2, 2, TERMS>(a, G, stream, launched);
