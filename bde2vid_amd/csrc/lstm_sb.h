@@ -151,24 +151,27 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     const unsigned long long real0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostics: 100 MHz reference clock)
 
     // this lane's pixel of each 32-pixel tile: q = t * 32 + (lane & 31) -> (row q / TC, column q % TC)
+    // (computed BEHIND the first halo request and the fragment prefetch -- lane_setup() below -- so that the DMA's flight covers it)
     const float inv_tc = 1.0f / (float)a.TC;
     int boff[NT], pix[NT];
+    f32x16 acc[NT];
+    auto lane_setup = [&]() {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int q = t * 32 + (lane & 31);
-        const int py = (int)(((float)q + 0.5f) * inv_tc), px = q - py * a.TC;
-        const bool ok = py < tr && px < tc;
-        pix[t] = ok ? (y0 + py) * a.W + x0 + px : -1;
-        const int cy = min(py, a.TR - 1), cx = min(px, a.TC - 1);   // (dead lanes read inside the tile)
-        boff[t] = SWZ ? cy * IW + cx : (cy * IW + cx) * SB_LDS_PITCH + hl * 16;      // (swizzled: the pixel index, see the tap loop)
-    }
+        for (int t = 0; t < NT; ++t) {
+            const int q = t * 32 + (lane & 31);
+            const int py = (int)(((float)q + 0.5f) * inv_tc), px = q - py * a.TC;
+            const bool ok = py < tr && px < tc;
+            pix[t] = ok ? (y0 + py) * a.W + x0 + px : -1;
+            const int cy = min(py, a.TR - 1), cx = min(px, a.TC - 1);   // (dead lanes read inside the tile)
+            boff[t] = SWZ ? cy * IW + cx : (cy * IW + cx) * SB_LDS_PITCH + hl * 16;      // (swizzled: the pixel index, see the tap loop)
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    };
     // (the accumulator scale is requested HERE, not in the tail where it is used: there it was a dependent load + vmcnt(0))
     const float unscale_v = TERMS == 2 ? a.acc_scale[0] : 1.f;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // pointwise operands of the (channel, pixel)s this wave finishes: register groups q = kp * QW .. + QW - 1 of its row tile
     float gv[NT][QW][4], cprev[NT][QW];
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
     const int nblk = (nslots + 63) >> 6;                 // 1-KiB DMA blocks of one tile
     const int tile_bytes = nblk * 1024;
     if (kchunks == 0) {
+        lane_setup();
         epi_load();
     } else {
         const unsigned char* inb = a.hin + g * a.hin_gs + n * a.hin_ns;
@@ -250,6 +254,8 @@ __global__ __launch_bounds__(256, 2) void lstm_sb_step_kernel(const LstmSbArgs a
         for (int q = 0; q < PF; ++q)
 #pragma unroll
             for (int k = 0; k < TERMS; ++k) af[q][k] = wfr[((long)min(q, S - 1) * TERMS + k) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        lane_setup();
         LSB_STAMP(1);
         for (int s = 0; s < stages; ++s) {
             if (!DB) {
