@@ -25,6 +25,8 @@ struct PackedLayer {
     long split_off(int terms) const { return terms == 2 ? sh_off : sb_off; }
     long split_sz(int terms) const { return terms == 2 ? sh_sz : sb_sz; }
     int sb_chunks = 0;                          // 16-channel chunks
+    long h3_off[2] = {-1, -1};                  // head3 packing (conv_sb.h, KS_HEAD3): [terms - 2], ten (row, column-group) taps of three columns x <= 5 channels
+    long h3_sz[2] = {0, 0};
     mutable int sb_used = 0;                    // the latest launch of this layer ran on conv_sb_kernel (bde_get_info "sb_*")
     int G_decide = 0;                           // a one-group view of a grouped layer: choose launch shapes as for this many groups
 };
@@ -183,6 +185,7 @@ struct bde_model {
     int wide = 1;                 // head_dim-16 attention levels on the fragment-layout chain (wideblock.h)
     int wide_fuse_qkv = 1;        // ... with the query frame's q | k | v computed inside the attention core (no GEMM launch of its own)
     int xcd_remap = 1;            // conv_sb workgroup order by XCD (conv_sb.h)
+    int head3 = 1;                // head convolution on the three-columns-per-chunk image (conv_sb.h, KS_HEAD3): 10 MFMA taps instead of 25
     int fuse_enc_sb = 1;          // encoder conv epilogue writes the SB16 input of its gate conv (no fp32 planes, no conversion pass)
     int conv_sb = 1;              // batched convolutions on the 16-bit matrix cores with split operands (conv_sb.h)
     int sb_terms = BDE_DEFAULT_SB_TERMS;   // format of every split operand (split.h): 2 = two fp16 terms (three MFMAs per fp32 block;

@@ -254,6 +254,34 @@ static void pack_split_bf16(Arena& ar, PackedLayer& pl, const std::vector<const 
     pack_split_terms(ar, pl, groups, 3);
     pack_split_terms(ar, pl, groups, 2);
 }
+// The head's 5x5 convolution over <= 5 input channels on the "three columns per chunk" image (conv_sb.h, KS_HEAD3): k = 5 jj + b of
+// a 16-channel chunk is channel b of column x - 2 + jj (jj < 3; k = 15 unused), so a kernel row is TWO MFMA taps -- columns kx = 0..2
+// at image column x, kx = 3..4 (+ a zero column) at x + 3 -- ten taps instead of twenty-five 16-channel chunks that are 11/16 zeros.
+// [co tile 32][tap = 2 ky + g][term][64 lanes][8]: lane l, element j: k = 8 (l >> 5) + j -> W[row][k % 5][ky][3 g + k / 5].
+// Same per-layer scale as the plain packing (the same weights).
+static void pack_head3(Arena& ar, PackedLayer& pl, const DenseLayer& d) {
+    if (d.KS != 5 || d.Cin * 3 > 15 || d.rows % 32 != 0) return;
+    const int ncot = d.rows / 32, taps = 10;
+    for (int terms = 2; terms <= 3; ++terms) {
+        const long sz = (long)ncot * taps * terms * 64 * 8 / 2;      // floats
+        const long off = ar.alloc(sz);
+        pl.h3_off[terms - 2] = off;
+        pl.h3_sz[terms - 2] = sz;
+        const float scale = split_scale({&d}, terms);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(ar.host.data() + off);
+        for (int ct = 0; ct < ncot; ++ct)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = ct * 32 + (l & 31), k = 8 * (l >> 5) + j;
+                        const int jj = k / 5, b = k - jj * 5, ky = tap >> 1, kx = 3 * (tap & 1) + jj;
+                        const float w = (k < 15 && b < d.Cin && kx < 5) ? d.w[((long)row * d.Cin + b) * 25 + ky * 5 + kx] : 0.f;
+                        unsigned short t3[3];
+                        split_terms(w, terms, scale, t3);
+                        for (int kk = 0; kk < terms; ++kk) dst[((((long)ct * taps + tap) * terms + kk) * 64 + l) * 8 + j] = t3[kk];
+                    }
+    }
+}
 
 // Channel chunking: generic convs CK = 8; the recurrent gate conv CK = 16 with chunks in groups of
 // four (one per wave); pointwise layers CK = 16 in groups of eight (any pw_gemm split-K factor).
@@ -413,6 +441,7 @@ static int build_packed(bde_model* m) {
         BDE_TRY(dense_convlayer(m, "head.", bc, c.num_bins, ks, &d));
         m->head = pack_layer(ar, {&d}, false);
         pack_split_bf16(ar, m->head, {&d});
+        pack_head3(ar, m->head, d);
     }
     const char* dirs[2] = {"forward_encoder", "backward_encoder"};
     for (int l = 0; l < L; ++l) {

@@ -119,6 +119,57 @@ static int run_conv(const bde_model* m, const ConvCall& cc, hipStream_t s) {
     return conv_launch_best(pl.KS, cc.stride, a, pl.G, s);
 }
 
+// The head ConvLayer (V5.py:116, submodules.py:105-114: 5x5, <= 5 bins -> basechannels, ReLU) of `N` voxel grids.  Where the packing
+// has it (pack_head3) and the scratch image fits, on the three-columns-per-chunk image: split_head3_kernel + conv_sb_kernel<KS_HEAD3>,
+// ten MFMA taps instead of twenty-five 16-channel chunks that are 11/16 zeros; otherwise the generic path (run_conv).
+static int run_head_conv(const bde_model* m, const float* ev, float* out, int N, int H, int W, hipStream_t s) {
+    const PackedLayer& pl = m->head;
+    Workspace& ws = const_cast<bde_model*>(m)->W();
+    const int ti = m->sb_terms - 2;
+    const bool h3 = m->head3 && m->conv_sb && (ti == 0 || ti == 1) && pl.h3_off[ti] >= 0 && pl.Cout == 32 && pl.KS == 5 && H >= 16 && W >= 16 &&
+                    (long)N * H * W >= 16384 && ws.sb != nullptr && (long)N * H * (W + 3) * sb_pix_bytes(m->sb_terms) <= ws.sb_bytes;
+    if (h3) {
+        BDE_TRY(split_head3(ev, ws.sb, N, pl.Cin, H, W, m->sb_terms, m->ovf(), s));
+        ConvArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = ws.sb;
+        a.wpk = m->P(pl.h3_off[ti]);
+        a.w_gs = pl.h3_sz[ti];
+        a.bias = m->P(pl.b_off);
+        a.bias_gs = pl.Cout;
+        a.out = out;
+        a.N = N;
+        a.Cin = pl.Cin;
+        a.Cout = pl.Cout;
+        a.Hs = a.Hin = a.Ho = H;
+        a.Ws = a.Win = W + 3;
+        a.Wo = W;
+        a.nchunks = 1;
+        a.act = ACT_RELU;
+        a.in_ns = (long)H * (W + 3) * sb_pix_bytes(m->sb_terms) / 4;
+        a.out_ns = a.res1_ns = a.res2_ns = (long)pl.Cout * H * W;
+        a.xcd_remap = m->xcd_remap;
+        a.sb_terms = m->sb_terms;
+        a.acc_scale = m->P(pl.sh_unscale_off);
+        a.zeros = m->P(m->zero_off);
+        bool launched = false;
+        BDE_TRY(conv_sb_launch_head3(a, s, &launched));
+        if (launched) {
+            pl.sb_used = 1;
+            return BDE_OK;
+        }
+    }
+    ConvCall hc;
+    hc.pl = &pl;
+    hc.in = ev;
+    hc.out = out;
+    hc.N = N;
+    hc.Hs = H;
+    hc.Ws = W;
+    hc.act = ACT_RELU;
+    return run_conv(m, hc, s);
+}
+
 // 1x1 conv over flattened [C][HW] planes
 static int run_pw(const bde_model* m, const PackedLayer* pl, const float* in, float* out, int N, long HW, int act,
                   const float* res1, const float* res2, int mask_w, int mask_pt, int mask_pl, hipStream_t s) {
@@ -1502,15 +1553,7 @@ static int forward_body(bde_model* m, int T, int B, int H, int W, hipStream_t s,
     if (part == PART_TAIL) return (m->debug_skip & 8) ? BDE_OK : decode_frames(m, tail_f0, tail_nf, T, B, H, W, s, PART_TAIL);
     // A. head (V5.py:116) and the first level's encoder convolution: PART_PRE
     if (part != PART_MAIN) {
-        ConvCall hc;
-        hc.pl = &m->head;
-        hc.in = ws.ev;
-        hc.out = ws.head;
-        hc.N = (int)TB;
-        hc.Hs = H;
-        hc.Ws = W;
-        hc.act = ACT_RELU;
-        { ProfScope ps(m, "head", s); BDE_TRY(run_conv(m, hc, s)); }
+        { ProfScope ps(m, "head", s); BDE_TRY(run_head_conv(m, ws.ev, ws.head, (int)TB, H, W, s)); }
         if (!(m->debug_skip & 16)) BDE_TRY(run_enc_gx(m, 0, ws.head, 0, (int)TB, T, B, H, W, s));
         if (part == PART_PRE) return BDE_OK;
     }

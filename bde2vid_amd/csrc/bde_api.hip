@@ -401,6 +401,7 @@ int bde_set_tuning(bde_model* m, const char* key, int64_t value) {
         return BDE_OK;
     }
     if (std::string(key) == "fuse_enc_sb") { m->fuse_enc_sb = (int)value; return BDE_OK; }
+    if (std::string(key) == "head3") { m->head3 = (int)value; return BDE_OK; }
     if (std::string(key) == "xcd_remap") { m->xcd_remap = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_two_streams") { m->lstm_two_streams = (int)value; return BDE_OK; }
     if (std::string(key) == "lstm_fuse_x") {
@@ -453,6 +454,7 @@ int bde_get_info(const bde_model* m, const char* key, int64_t* value) {
     else if (k == "winblock_sb") *value = m->winblock_sb;
     else if (k == "wide") *value = m->wide;
     else if (k == "conv_sb") *value = m->conv_sb;
+    else if (k == "head3") *value = m->head3;
     else if (k == "lstm_sb") *value = m->lstm_sb_mode;
     else if (k == "lstm_sbk") *value = m->use_lstm_sbk;
     else if (k == "lstm_fuse_x") *value = m->lstm_fuse_x;
@@ -716,9 +718,7 @@ int32_t bde_metric_scratch_doubles(int32_t N) { return N * METRIC_BLOCKS; }
 int bde_op_head(bde_model* m, const float* in, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
     BDE_REQUIRE(m && m->finalized && in && out, "bad argument");
     TuningScope ts(&m->tune);
-    ConvCall c;
-    c.pl = &m->head; c.in = in; c.out = out; c.N = N; c.Hs = H; c.Ws = W; c.act = ACT_RELU;
-    return run_conv(m, c, (hipStream_t)stream);
+    return run_head_conv(m, in, out, N, H, W, (hipStream_t)stream);
 }
 
 int bde_op_encoder_conv(bde_model* m, int32_t level, int32_t dir, const float* in, int32_t N, int32_t H, int32_t W,

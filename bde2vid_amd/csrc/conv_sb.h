@@ -77,8 +77,60 @@ int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, un
     BDE_HIP(hipGetLastError());
     return BDE_OK;
 }
+// fp32 voxel grids [N][C <= 5][H][W] -> the head3 image (api_pack.h, pack_head3): SB16 with ONE chunk and W + 3 columns,
+// [N][H][W + 3][terms][16]: channel k = 5 jj + b of pixel (y, e) = in[n][b][y][e - 2 + jj] (0 outside the row; k = 15: 0) -- three
+// columns of the grid per chunk, so that a 5-wide kernel row is two MFMA taps.  grid (ceil(H (W + 3) / 128), 1, N), 256 threads =
+// 128 pixels x 2 halves of the chunk; pieces staged through LDS as in split_bf16_kernel.
+template <int TERMS>
+__global__ __launch_bounds__(256) void split_head3_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int C, int H, int W,
+                                                          unsigned* ovf) {
+    const int WE = W + 3;
+    const long HWE = (long)H * WE;
+    const int half = threadIdx.x >> 7, pl = threadIdx.x & 127;
+    const long p0 = (long)blockIdx.x * 128;
+    const long p = min(p0 + pl, HWE - 1);
+    const long n = blockIdx.z;
+    const int y = (int)(p / WE), e = (int)(p - (long)y * WE);
+    unsigned short t[8][TERMS];
+    float gm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = half * 8 + j, jj = k / 5, b = k - jj * 5, x = e - 2 + jj;
+        const bool ok = k < 15 && b < C && x >= 0 && x < W;
+        const float v = ok ? in[((n * C + b) * H + y) * (long)W + x] : 0.f;
+        if (TERMS == 2) gm = sb_guard_max(gm, v);
+        sb_split_dev<TERMS>(v, t[j]);
+    }
+    if (TERMS == 2) sb_guard_flush(gm, ovf);
+    constexpr int PB = 32 * TERMS, PITCH = PB + 16, PPP = 2 * TERMS;
+    __shared__ __align__(16) unsigned char stg[128 * (32 * TERMS + 16)];
+#pragma unroll
+    for (int k = 0; k < TERMS; ++k) {
+        uint4 v;
+        v.x = t[0][k] | ((unsigned)t[1][k] << 16);
+        v.y = t[2][k] | ((unsigned)t[3][k] << 16);
+        v.z = t[4][k] | ((unsigned)t[5][k] << 16);
+        v.w = t[6][k] | ((unsigned)t[7][k] << 16);
+        *reinterpret_cast<uint4*>(stg + pl * PITCH + k * 32 + half * 16) = v;
+    }
+    __syncthreads();
+    const int npix = (int)min(128L, HWE - p0);
+    unsigned char* ob = reinterpret_cast<unsigned char*>(out + ((n * HWE + p0) * TERMS) * 16);
+    for (int it = threadIdx.x; it < npix * PPP; it += 256) {
+        const int q = it % PPP, px = it / PPP;
+        *reinterpret_cast<uint4*>(ob + (long)px * PB + q * 16) = *reinterpret_cast<const uint4*>(stg + px * PITCH + q * 16);
+    }
+}
+int split_head3(const float* in, void* out, long N, int C, int H, int W, int terms, unsigned* ovf, hipStream_t s) {
+    const dim3 grid((unsigned)cdivl((long)H * (W + 3), 128), 1, (unsigned)N);
+    if (terms == 2) hipLaunchKernelGGL(split_head3_kernel<2>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, H, W, ovf);
+    else hipLaunchKernelGGL(split_head3_kernel<3>, grid, dim3(256), 0, s, in, (unsigned short*)out, C, H, W, ovf);
+    BDE_HIP(hipGetLastError());
+    return BDE_OK;
+}
 #else
 int split_bf16(const float* in, void* out, long N, int C, long HW, int terms, unsigned* ovf, hipStream_t s);   // sb_tu.hip
+int split_head3(const float* in, void* out, long N, int C, int H, int W, int terms, unsigned* ovf, hipStream_t s);
 #endif
 // ConvLSTM pointwise tail for the split-bf16 recurrent step (submodules.py:320-332): gates = gx (x-part incl. bias) + gh
 // (h-part, from conv_sb_kernel; nullptr at the first step, h = 0), chunk order i, f, o, g; c = sigma(f) c + sigma(i) tanh(g);
@@ -156,6 +208,7 @@ static inline long split_bf16_bytes(long N, int C, long HW, int terms = 3) { ret
 // a.in = SB16 activations (as float*), a.wpk = split packed weights; group / frame strides of `in` in BYTES / 4 (floats).
 // DB: two halo buffers in LDS, the next chunk's DMA in flight during the MFMAs of the current one -- for the small launches
 // of the recurrent step, where a CU holds one or two workgroups and nobody else covers the staging.
+constexpr int KS_HEAD3 = 53;                              // conv_sb_kernel's KS for the head3 form (see the kernel)
 #ifndef CONV_SB_STAGGER
 #define CONV_SB_STAGGER 0
 #endif
@@ -172,7 +225,12 @@ static inline long split_bf16_bytes(long N, int C, long HW, int terms = 3) { ret
 #endif
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int MAXI, bool DB, int TERMS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs a) {
-    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    // KS == KS_HEAD3: the head's 5x5 convolution on its three-columns-per-chunk image (api_pack.h, pack_head3; split_head3_kernel
+    // below): ten taps (ky, g) at rows y + ky - 2 and image columns x + 3 g -- a footprint of 5 rows x 4 columns, no column padding
+    // (the image carries its own two columns of left context).  2-D pixel tiles only.
+    constexpr bool HEAD3 = KS == KS_HEAD3;
+    constexpr int KY = HEAD3 ? 5 : KS, KX = HEAD3 ? 4 : KS;            // footprint of the taps in input pixels
+    constexpr int PAD = KY / 2, PADX = HEAD3 ? 0 : KS / 2, TAPS = HEAD3 ? 10 : KS * KS;
     constexpr int SB_PIX_BYTES = sb_pix_bytes(TERMS), SB_LDS_PITCH = sb_lds_pitch(TERMS), SLOTS = sb_lds_slots(TERMS);
     constexpr int BN = WN * NT * 32;
     extern __shared__ __align__(16) unsigned char sb_lds[];
@@ -205,9 +263,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
         ep_y0 = y0; ep_x0 = x0;
         p_end = HW;
         iy0 = y0 * STRIDE - PAD;
-        ix0 = x0 * STRIDE - PAD;
-        R = (TR - 1) * STRIDE + KS;
-        IW = (TC - 1) * STRIDE + KS;
+        ix0 = x0 * STRIDE - PADX;
+        R = (TR - 1) * STRIDE + KY;
+        IW = (TC - 1) * STRIDE + KX;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int q = (wn * NT + t) * 32 + (lane & 31);
@@ -351,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_sb_kernel(const ConvArgs
             // it (fewer live registers, one more wave per SIMD) -- ISA of round 4: `global_load; s_waitcnt vmcnt(0); v_mfma` at
             // every tap, an L2 round trip in front of each six MFMAs.
             __builtin_amdgcn_sched_barrier(0);
-            const int ky = tap / KS, kx = tap - ky * KS;
+            const int ky = HEAD3 ? tap >> 1 : tap / KS, kx = HEAD3 ? 3 * (tap & 1) : tap - (tap / KS) * KS;
             if (!(CONV_SB_DBG & 2) || tap == 0)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -572,7 +630,8 @@ static int conv_sb_launch_2d(ConvArgs a, int G, hipStream_t stream, bool* launch
     a.row_tiles = 0;
     a.tile_cols = conv_sb_tile_cols(BN, a.Ho, a.Wo);
     const int TR = BN / a.tile_cols;
-    const long halo = (long)((TR - 1) * STRIDE + KS) * ((a.tile_cols - 1) * STRIDE + KS);
+    constexpr int KY = KS == KS_HEAD3 ? 5 : KS, KX = KS == KS_HEAD3 ? 4 : KS;       // footprint of the taps (conv_sb_kernel)
+    const long halo = (long)((TR - 1) * STRIDE + KY) * ((a.tile_cols - 1) * STRIDE + KX);
     const long blocks = (halo * sb_lds_slots(TERMS) + 63) / 64;
     const long per_wave = (blocks + WM * WN - 1) / (WM * WN);
     if (halo * sb_lds_pitch(TERMS) > 78 * 1024 || per_wave > 24) return BDE_OK;
@@ -630,8 +689,16 @@ int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t str
     if (KS == 5 && stride == 2) return conv_sb_launch_ks<5, 2, 3>(a, G, stream, launched);
     return BDE_OK;
 }
+// the head's convolution on its head3 image: a.in = that image (a.Win = a.Ws = W + 3, one chunk), a.wpk = the head3 packing
+int conv_sb_launch_head3(const ConvArgs& a, hipStream_t stream, bool* launched) {
+    *launched = false;
+    if (a.Cout != 32 || a.Ho < 16 || a.Wo < 16) return BDE_OK;
+    if (a.sb_terms == 2) return conv_sb_launch_2d<KS_HEAD3, 1, 1, 2, 1, 4, 2>(a, 1, stream, launched);
+    return conv_sb_launch_2d<KS_HEAD3, 1, 1, 2, 1, 4, 3>(a, 1, stream, launched);
+}
 #else
 int conv_sb_launch(int KS, int stride, const ConvArgs& a, int G, hipStream_t stream, bool* launched);   // sb_tu.hip
+int conv_sb_launch_head3(const ConvArgs& a, hipStream_t stream, bool* launched);
 #endif
 
 }  // namespace bde

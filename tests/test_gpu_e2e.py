@@ -534,7 +534,7 @@ def test_round3_kernels_agree_with_the_kernels_they_replace():
         assert [m.get_info(f'sb_lstm{l}') for l in range(3)] == [1, 1, 1]
         terms = m.get_info('sb_terms')                                 # 2 unless BDE_SB_TERMS says otherwise
         for key, off, on in (('lstm_sbk', 0, 1), ('winblock_sb', 0, 1), ('wide_fuse_qkv', 0, 1), ('lstm_two_streams', 1, 0),
-                             ('lstm_fuse_x', 0, 1), ('sb_terms', 5 - terms, terms), ('conv_sb', 0, 1), ('wide_kv_sb', 0, 1), ('wide_fuse_mlp', 0, 1), ('wide_fuse_fc2', 0, 1), ('wide_core2', 0, 1), ('wide_spl', 0, 1)):
+                             ('lstm_fuse_x', 0, 1), ('sb_terms', 5 - terms, terms), ('conv_sb', 0, 1), ('wide_kv_sb', 0, 1), ('wide_fuse_mlp', 0, 1), ('wide_fuse_fc2', 0, 1), ('wide_core2', 0, 1), ('wide_spl', 0, 1), ('head3', 0, 1)):
             m.set_tuning(key, off)
             try:
                 y = torch.stack(m(inp))
@@ -545,6 +545,7 @@ def test_round3_kernels_agree_with_the_kernels_they_replace():
             assert torch.equal(y, y2), key
         last = torch.stack(m(inp))
         assert torch.equal(last, base), maxabs(last, base)
+        assert m.get_info('head3') == 1
 
 
 def _scaled_head_model(scale):
