@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
 // weight fragments (the four waves of a workgroup ask for the same ones: L1), MFMAs and 16-byte stores.  The sum over k runs in the
 // same order as in tokgemm_sb_kernel: identical results.  K = 256.
 #ifndef TOKGEMM_SB_RGN
-#define TOKGEMM_SB_RGN 12
+#define TOKGEMM_SB_RGN 6
 #endif
 #ifndef TOKGEMM_SB_PD
 #define TOKGEMM_SB_PD 3
@@ -454,27 +454,25 @@ __global__ __launch_bounds__(256) void tokgemm_sb_kernel(const TokGemmArgs a) {
 #ifndef TOKGEMM_SB_MT
 #define TOKGEMM_SB_MT 4
 #endif
+#ifndef TOKGEMM_SB_NTT
+#define TOKGEMM_SB_NTT 2
+#endif
 #ifndef TOKGEMM_SB_OCC
 #define TOKGEMM_SB_OCC 1
 #endif
-template <int RGN, int MT>
+template <int RGN, int MT, int NTT>
 __global__ __launch_bounds__(256, TOKGEMM_SB_OCC) void tokgemm_sb_rows_kernel(const TokGemmArgs a) {
+    // NTT token tiles per wave: every weight fragment feeds NTT MFMAs -- the four waves of a workgroup walk the same rows, and each pulls
+    // its own copy of the fragments through the CU's vector-memory return path (64 B/clk): that path, not the matrix pipe, is what one
+    // token tile per wave was bound by (128 us at any occupancy, prefetch depth or store pattern).
     constexpr int KS = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g4 = lane >> 4, col = lane & 15;
     const int b = blockIdx.z;
     const int ngk = a.K >> 4, ngm = a.M >> 4;
-    const int tile = min((int)blockIdx.x * 4 + wave, a.ntile - 1);          // (a wave past the last tile repeats it and stores nothing)
-    const bool tile_live = (int)blockIdx.x * 4 + wave < a.ntile;
+    const int tile0 = ((int)blockIdx.x * 4 + wave) * NTT;                   // (a tile past the last one repeats it and stores nothing)
     const int rtg0 = blockIdx.y * MT * RGN;
     const float unscale_v = a.w_unscale[0];
-    const wf4* xp = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)tile * ngk) * 64 + lane;
-    wf4 xv[KS][2];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        xv[k][0] = xp[(long)(2 * k) * 64];
-        xv[k][1] = xp[(long)(2 * k + 1) * 64];
-    }
     const sb8* wbase = reinterpret_cast<const sb8*>(a.wS) + lane;
     auto wfrag = [&](int rt, int k, int t) { return wbase[(((long)min(rt, ngm - 1) * KS + k) * 2 + t) * 64]; };
     const float* lsum = a.lnsum ? a.lnsum : a.bias;        // (pointer select: no load under a branch)
@@ -490,34 +488,47 @@ __global__ __launch_bounds__(256, TOKGEMM_SB_OCC) void tokgemm_sb_rows_kernel(co
 #pragma unroll
             for (int t = 0; t < 2; ++t) av[j][m][t] = wfrag(rtg0 + m, j, t);
     __builtin_amdgcn_sched_barrier(0);
-    // the token tile: statistics and split, once
-    float s1 = 0.f, s2 = 0.f, gm = 0.f;
-    sb8 bfr[KS][2];
+    // the token tiles: statistics and split, once
+    float gm = 0.f, mu[NTT], rstd[NTT];
+    sb8 bfr[NTT][KS][2];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const wf4 x0 = xv[k][0], x1 = xv[k][1];
-        s1 += ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
-        s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
-              ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
-        unsigned t[4][2];
-        ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
-        ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
-        ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
-        ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
+    for (int tt = 0; tt < NTT; ++tt) {
+        const int tile = min(tile0 + tt, a.ntile - 1);
+        const wf4* xp = reinterpret_cast<const wf4*>(a.x + b * a.x_bs) + ((long)tile * ngk) * 64 + lane;
+        wf4 xv[KS][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) bfr[k][q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+        for (int k = 0; k < KS; ++k) {
+            xv[k][0] = xp[(long)(2 * k) * 64];
+            xv[k][1] = xp[(long)(2 * k + 1) * 64];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const wf4 x0 = xv[k][0], x1 = xv[k][1];
+            s1 += ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+            s2 += ((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+                  ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3]));
+            unsigned t[4][2];
+            ws_split_pair_g<2>(x0[0], x0[1], t[0], gm);
+            ws_split_pair_g<2>(x0[2], x0[3], t[1], gm);
+            ws_split_pair_g<2>(x1[0], x1[1], t[2], gm);
+            ws_split_pair_g<2>(x1[2], x1[3], t[3], gm);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bfr[tt][k][q] = sb8{(int)t[0][q], (int)t[1][q], (int)t[2][q], (int)t[3][q]};
+        }
+        mu[tt] = 0.f;
+        rstd[tt] = 1.f;
+        if (a.lnsum) {
+            float u = s1, v = s2;
+            u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+            u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+            const float mean = u / (float)a.K;
+            const float var = fmaxf(v / (float)a.K - mean * mean, 0.f);
+            mu[tt] = mean;
+            rstd[tt] = __builtin_amdgcn_rsqf(var + 1e-5f);
+        }
     }
     sb_guard_flush(gm, a.ovf);
-    float mu = 0.f, rstd = 1.f;
-    if (a.lnsum) {
-        float u = s1, v = s2;
-        u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
-        u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
-        const float mean = u / (float)a.K;
-        const float var = fmaxf(v / (float)a.K - mean * mean, 0.f);
-        mu = mean;
-        rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-    }
     const float unscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, unscale_v)));
     constexpr int SP = MT * 16 + 4;                       // floats per token in the staging tile (+ 4: bank spread)
     __shared__ __align__(16) float stg_all[4][16 * (MT * 16 + 4)];
@@ -536,12 +547,14 @@ __global__ __launch_bounds__(256, TOKGEMM_SB_OCC) void tokgemm_sb_rows_kernel(co
                 ss[m][r] = lsum[row0 + r];
             }
         }
-        f32x4 acc[MT];
+        f32x4 acc[NTT][MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[tt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            // the next k-step's fragments (the next group's first ones behind the last step): requested here, used a step later
+            // the fragments of k-step k + PD (the next group's first ones behind the last steps): requested here, used PD steps later
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -549,34 +562,40 @@ __global__ __launch_bounds__(256, TOKGEMM_SB_OCC) void tokgemm_sb_rows_kernel(co
                     av[(k + PD) % RING][m][t] = k + PD < KS ? wfrag(rt0 + m, k + PD, t) : wfrag(rt0 + MT + m, k + PD - KS, t);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = sb_mma16<2>(av[k % RING][m], bfr[k], acc[m]);
+            for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[tt][m] = sb_mma16<2>(av[k % RING][m], bfr[tt][k], acc[tt][m]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the group's 16 tokens x (MT x 16) rows go out through the wave's corner of LDS: a lane holds four rows of ONE token, so stored
-        // directly an instruction is sixteen 64-byte halves of sixteen different lines (the launch then FETCHES 240 MB to fill the
+        // a group's 16 tokens x (MT x 16) rows per token tile go out through the wave's corner of LDS: a lane holds four rows of ONE token,
+        // so stored directly an instruction is sixteen 64-byte halves of sixteen different lines (the launch then FETCHES 240 MB to fill the
         // lines it half-writes: rocprofv3 FETCH_SIZE); read back token-major, sixteen lanes write the 16 MT rows x 4 bytes of a token.
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v;
+        for (int tt = 0; tt < NTT; ++tt) {
+            const int tile = tile0 + tt;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float y = acc[m][r] * unscale;
-                if (a.lnsum) y = rstd * (y - mu * ss[m][r]);
-                v[r] = act_apply(y + bb[m][r], a.act);
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float y = acc[tt][m][r] * unscale;
+                    if (a.lnsum) y = rstd[tt] * (y - mu[tt] * ss[m][r]);
+                    v[r] = act_apply(y + bb[m][r], a.act);
+                }
+                *reinterpret_cast<f32x4*>(stg + col * SP + m * 16 + g4 * 4) = v;
             }
-            *reinterpret_cast<f32x4*>(stg + col * SP + m * 16 + g4 * 4) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        constexpr int LPT = MT * 4;                       // lanes (16-byte pieces) per token
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            constexpr int LPT = MT * 4;                       // lanes (16-byte pieces) per token
 #pragma unroll
-        for (int j = 0; j < 16 * LPT / 64; ++j) {
-            const int tk = (j * 64 + lane) / LPT, pc = (j * 64 + lane) % LPT;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + tk * SP + pc * 4);
-            const int tokk = tile * 16 + tk, rt = rt0 + (pc >> 2);
-            if (tile_live && tokk < a.HW && rt < ngm)
-                *reinterpret_cast<f32x4*>(a.out_tok + b * a.out_bs + (long)tokk * a.M + (long)rt0 * 16 + pc * 4) = v;
+            for (int j = 0; j < 16 * LPT / 64; ++j) {
+                const int tk = (j * 64 + lane) / LPT, pc = (j * 64 + lane) % LPT;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + tk * SP + pc * 4);
+                const int tokk = tile * 16 + tk, rt = rt0 + (pc >> 2);
+                if (tile < a.ntile && tokk < a.HW && rt < ngm)
+                    *reinterpret_cast<f32x4*>(a.out_tok + b * a.out_bs + (long)tokk * a.M + (long)rt0 * 16 + pc * 4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 static bool tokgemm_sb_fits(const TokGemmArgs& a) {
@@ -589,9 +608,9 @@ static int tokgemm_sb_launch(const TokGemmArgs& a, int B, hipStream_t s) {
     //  per SIMD; four row tiles: 212, two waves)
     (void)tiles;
     if (TOKGEMM_SB_RGN > 0 && a.K == 256 && (long)a.ntile * B >= 256 && ngm >= TOKGEMM_SB_MT * TOKGEMM_SB_RGN) {
-        // the T-batched launch: a wave keeps its split token tile and walks TOKGEMM_SB_RGN groups of TOKGEMM_SB_MT row tiles
-        hipLaunchKernelGGL((tokgemm_sb_rows_kernel<TOKGEMM_SB_RGN, TOKGEMM_SB_MT>), dim3(cdiv(a.ntile, 4), cdiv(ngm, TOKGEMM_SB_MT * TOKGEMM_SB_RGN), B),
-                           dim3(256), 0, s, a);
+        // the T-batched launch: a wave keeps its split token tiles and walks TOKGEMM_SB_RGN groups of TOKGEMM_SB_MT row tiles
+        hipLaunchKernelGGL((tokgemm_sb_rows_kernel<TOKGEMM_SB_RGN, TOKGEMM_SB_MT, TOKGEMM_SB_NTT>),
+                           dim3(cdiv(a.ntile, 4 * TOKGEMM_SB_NTT), cdiv(ngm, TOKGEMM_SB_MT * TOKGEMM_SB_RGN), B), dim3(256), 0, s, a);
         BDE_HIP(hipGetLastError());
         return BDE_OK;
     }
