@@ -283,9 +283,16 @@ def test_two_dimensional_tiles_on_odd_maps(model_a):
         x = torch.from_numpy(dense_like((N, 5, H, W), seed))
         with torch.no_grad():
             ref = O.conv_layer(x, sd[O.P + 'head.conv2d.weight'], sd[O.P + 'head.conv2d.bias'], 1, 'relu')
-        y = ops.head(m, x.cuda())
-        assert m.get_info('sb_head') == 1, (N, H, W)
+        y = ops.head(m, x.cuda())                        # head3: three grid columns per chunk, ten MFMA taps (csrc/conv_sb.h, KS_HEAD3)
+        assert m.get_info('sb_head') == 1 and m.get_info('head3') == 1, (N, H, W)
         assert maxabs(y, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), ('head', N, H, W)
+        m.set_tuning('head3', 0)                         # ... and the generic split convolution (25 taps on a 16-channel chunk)
+        try:
+            y0 = ops.head(m, x.cuda())
+        finally:
+            m.set_tuning('head3', 1)
+        assert maxabs(y0, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), ('head, generic', N, H, W)
+        assert maxabs(y, y0) <= 2e-5 * max(1.0, float(ref.abs().max())), ('head3 vs generic', N, H, W)
     for (N, H, W, seed) in ((10, 74, 90, 1210), (8, 66, 130, 1211), (3, 34, 490, 1212), (24, 38, 36, 1213)):
         x = torch.from_numpy(dense_like((N, 32, H, W), seed))
         for d, name in enumerate(('forward_encoder', 'backward_encoder')):
