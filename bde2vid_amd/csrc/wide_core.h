@@ -149,11 +149,15 @@ __global__ __launch_bounds__(256, 2) void wide_core_kernel(const WideCoreArgs a)
             const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
             L = xcd * q + min(xcd, rem) + (lin >> 3);
         }
-        win = (int)(L % gx);
-        head = (int)((L / gx) % gy);
-        b = (int)(L / (gx * gy));
+        // (L < 2^20, divisors < 2^10: floor((L + 0.5) / d) through one v_rcp_f32 is exact -- an integer division by a run-time
+        //  divisor is ~40 instructions, three of them at the head of every launch of the sequential chain)
+        const unsigned q1 = (unsigned)(((float)L + 0.5f) * __builtin_amdgcn_rcpf((float)gx));
+        win = (int)(L - q1 * gx);
+        const unsigned q2 = (unsigned)(((float)q1 + 0.5f) * __builtin_amdgcn_rcpf((float)gy));
+        head = (int)(q1 - q2 * gy);
+        b = (int)q2;
     }
-    const int wi = win / a.nWw, wj = win - wi * a.nWw;
+    const int wi = (int)(((float)win + 0.5f) * __builtin_amdgcn_rcpf((float)a.nWw)), wj = win - wi * a.nWw;   // (exact, as above)
     const int step = a.dilated ? 2 : 1;
     const int c0 = head * HD;
     const int nkey = a.D * ATT_TOK;

@@ -102,9 +102,10 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(const MlpFusedArgs a) {
             const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
             L = xcd * q + min(xcd, rem) + (lin >> 3);
         }
-        tile = (int)(L % gx);
-        quarter = (int)((L / gx) & 3u);
-        b = (int)(L / (gx * 4u));
+        const unsigned q1 = (unsigned)(((float)L + 0.5f) * __builtin_amdgcn_rcpf((float)gx));   // (exact: wide_core.h)
+        tile = (int)(L - q1 * gx);
+        quarter = (int)(q1 & 3u);
+        b = (int)(q1 >> 2);
     }
     const int tok = tile * 16 + col;
     WM_STAMP(0);
