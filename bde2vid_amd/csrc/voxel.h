@@ -278,7 +278,10 @@ __global__ __launch_bounds__(1024) void voxel_tile_kernel(const void* __restrict
 // count.  Per-event arithmetic as in the kernels above (t_norm is computed once, in the bucketing pass).
 constexpr int VB_CHUNK = 4096;              // events per bucketing workgroup (256 threads x 16)
 constexpr int VB_MAX_TILES = 1024;
-constexpr long VB_TILE_LDS = 128 * 1024;    // LDS of one tile workgroup on the bucketed path (64 KB = two workgroups per CU measured
+#ifndef VB_TILE_LDS_BYTES
+#define VB_TILE_LDS_BYTES (128 * 1024)
+#endif
+constexpr long VB_TILE_LDS = VB_TILE_LDS_BYTES;    // LDS of one tile workgroup on the bucketed path (64 KB = two workgroups per CU measured
                                             // slower at every resolution: the pass pays ~13 us per workgroup, not per byte)
 constexpr unsigned VB_NAN_WINDOW = 0x40000000u;     // flag on the last run offset of a window's first chunk
 struct VoxelRec { unsigned a; float tn; };  // a = cell (13 bits) | tile << 13 | polarity sign << 31
